@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- input GB/s scanned by the PFAC hot path on N MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic input that is ALREADY RESIDENT in
+HBM: zero the control/look-back words, run the scan kernel over this rank's shard (1 GiB owned +
+max_pat_len-1 bytes of halo), read back the exact match count, and (N > 1) all-gather the per-rank
+counts (the one exchange the sharded path needs to place records).  Weak scaling: every rank owns
+1 GiB, so the global stream is N GiB.  The workload is BASELINE.json configs[1]: pattern file
+`experimentpattern`, input = the reference's `1M` text (402-byte period) tiled to 1 GiB, 1 stream per
+GPU, PHF width 256.  Rank 0 builds the table on the host (C) and broadcasts its image with RCCL.
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+  roofline     algorithmic bytes (1 B per input byte) / kernel time measured with HIP events on the
+               stream the kernel runs on, against the 8 TB/s HBM3E peak
+  cpu_baseline serial Aho-Corasick (oracle/ac_serial.c, the CHECKER, kind "port") timed on this
+               host, one core, on a bounded sample of the same workload (N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+DATA = os.path.join(REPO, "tests", "golden", "data")
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GIB = 1 << 30
+
+WORKLOADS = {
+    # name: (pattern fixture, input kind, description)
+    "text1g_experimentpattern": ("experimentpattern", "text", "experimentpattern (4 patterns) x reference 1M text tiled to 1 GiB/GPU"),
+    "text1g_bytefile10000": ("bytefile_10000byte", "text", "bytefile/10000byte (1376 patterns) x reference 1M text tiled to 1 GiB/GPU"),
+    "rand1g_experimentpattern": ("experimentpattern", "rand", "experimentpattern x splitmix64 random bytes, 1 GiB/GPU"),
+    "text1g_dictionary": ("xaa+xab+xac+xad", "text", "7989-word dictionary (xaa..xad) x reference 1M text tiled to 1 GiB/GPU"),
+}
+
+
+def pattern_path(name, tmpdir):
+    if "+" not in name:
+        return os.path.join(DATA, name)
+    p = os.path.join(tmpdir, "all.pat")
+    with open(p, "wb") as f:
+        for part in name.split("+"):
+            f.write(open(os.path.join(DATA, part), "rb").read())
+    return p
+
+
+def cpu_baseline(pat_path, kind, para, seconds=12.0):
+    """Serial Aho-Corasick on ONE host core over a bounded sample of the same workload."""
+    from orc import Oracle, lib
+    from phfpfac_amd.matcher import splitmix64_bytes, tiled_bytes
+    import ctypes as C
+    L = lib()
+    o = Oracle(pat_path, 1, 1)
+    ac = L.ac_build(o.m)
+    sample = 256 << 20
+    buf = tiled_bytes(sample, para) if kind == "text" else splitmix64_bytes(sample, 0x5048465046414331)
+    chk = C.c_uint64(0)
+    L.ac_scan_count(ac, buf.ctypes.data, 1 << 20, C.byref(chk))          # warm the DFA
+    passes, t0, matches = 0, time.perf_counter(), 0
+    while True:
+        matches = L.ac_scan_count(ac, buf.ctypes.data, sample, C.byref(chk))
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or passes >= 64:
+            break
+    L.ac_free(ac)
+    o.close()
+    gbs = passes * sample / dt / 1e9
+    return {"value": round(gbs, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} pass(es) over the first 256 MiB of the workload ({dt:.1f} s), serial Aho-Corasick "
+                      f"full-DFA, {matches} matches/pass; host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="text1g_experimentpattern", choices=sorted(WORKLOADS))
+    ap.add_argument("--bytes-per-gpu", type=int, default=GIB)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also time the other workloads (short) and report them")
+    args = ap.parse_args()
+
+    import torch
+    from phfpfac_amd import GpuMatcher, PfacTable
+    from phfpfac_amd import dist as pdist
+    from phfpfac_amd.matcher import tiled_bytes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the PFAC scan has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import tempfile
+    tmpdir = tempfile.mkdtemp()
+    para = open(os.path.join(DATA, "paragraph402"), "rb").read()
+    per = args.bytes_per_gpu
+    n_total = per * world
+
+    def run_workload(name, steps, warmup):
+        pat_name, kind, desc = WORKLOADS[name]
+        ppath = pattern_path(pat_name, tmpdir)
+        g = GpuMatcher(local_rank, 1)
+        if world > 1:
+            table = PfacTable.from_file(ppath, 256) if rank == 0 else None
+            blob, table = pdist.broadcast_table(table, dev, 0)             # RCCL broadcast of the table image
+            torch.cuda.synchronize()
+            g.load_table_device(blob, blob.numel(), 0, host_table=table)
+        else:
+            table = PfacTable.from_file(ppath, 256)
+            g.load_table(table)
+        lo, hi, end = pdist.shard_read_range(n_total, rank, world, table.halo)
+        n_owned, n_avail = hi - lo, end - lo
+        buf = torch.empty(n_avail + 4096, dtype=torch.uint8, device=dev)
+        if kind == "text":
+            g.fill_tiled(buf, n_avail, para, phase=lo % len(para))
+        else:
+            g.fill_random(buf, (n_avail + 7) // 8 * 8, 0x5048465046414331 + lo // 8)
+        cap = max(n_owned // 8, 1 << 20)
+        g.reserve(0, 0, cap)
+        n = g.scan_resident(n_owned, n_avail, d_input=buf)                 # sizes the record buffer, warms up
+        # parity spot check (outside the timed region): first 4 MiB of this shard vs the CPU oracle
+        from orc import Oracle, match_checksum
+        m = min(4 << 20, n_owned)
+        nm = g.scan_resident(m, min(n_avail, m + table.halo), d_input=buf)
+        host = buf[: min(n_avail, m + table.halo)].cpu().numpy()
+        o = Oracle(ppath, 1, 1)
+        opos, oids = o.scan_spec(host, None)
+        keep = opos < m
+        o.close()
+        ok = (nm == int(keep.sum())) and g.checksum(nm) == match_checksum(opos[keep], oids[keep])
+        if not ok:
+            raise SystemExit(f"rank {rank}: PARITY FAILURE on workload {name}: gpu {nm} vs oracle {int(keep.sum())}")
+
+        def step():
+            g.scan_async(n_owned, n_avail, d_input=buf)
+            cnt, _ = g.scan_finish(0)
+            if world > 1:
+                pdist.gather_counts(cnt, dev)
+            return cnt
+
+        for _ in range(warmup):
+            step()
+        kern_ms = []
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cnt = step()
+            kern_ms.append(g.elapsed_ms(0))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            tot = torch.tensor([cnt], dtype=torch.int64, device=dev)
+            dist.all_reduce(tot)
+            cnt_all = int(tot.item())
+        else:
+            cnt_all = cnt
+        info = g.info()
+        g.close()
+        del buf
+        torch.cuda.empty_cache()
+        k_avg = float(np.mean(kern_ms))
+        return {"name": name, "desc": desc, "ppath": ppath, "kind": kind, "dt": dt, "kernel_ms": k_avg,
+                "kernel_ms_min": float(np.min(kern_ms)), "matches": cnt_all, "info": info, "table": table,
+                "n_owned": n_owned}
+
+    res = run_workload(args.workload, args.steps, args.warmup)
+    value = n_total * args.steps / res["dt"] / 1e9
+    achieved = res["n_owned"] / (res["kernel_ms"] * 1e-3) / 1e9
+    out = {
+        "metric": "input GB/s scanned", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": res["desc"], "bytes_per_gpu": per, "global_bytes": n_total, "streams_per_gpu": 1,
+                   "phf_width": 256, "patterns": res["table"].n_patterns, "states": res["table"].state_num,
+                   "kernel_variant": res["info"]["variant"], "tile_bytes": res["info"]["tile_bytes"],
+                   "grid_blocks": res["info"]["grid_blocks"], "lds_bytes": res["info"]["lds_bytes"],
+                   "parallelism": f"input-sharded x{world}, halo {res['table'].halo} B",
+                   "matches_per_step": res["matches"], "parity": "count+checksum vs CPU oracle on 4 MiB/rank: ok"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "pfac_scan_kernel", "kernel_ms_avg": round(res["kernel_ms"], 4),
+                     "kernel_ms_min": round(res["kernel_ms_min"], 4),
+                     "algorithmic_bytes_per_launch": res["n_owned"]},
+    }
+    if args.extra:
+        out["other_workloads"] = {}
+        for name in sorted(WORKLOADS):
+            if name == args.workload:
+                continue
+            r = run_workload(name, max(3, args.steps // 4), 1)
+            out["other_workloads"][name] = {
+                "value_gbs": round(n_total * max(3, args.steps // 4) / r["dt"] / 1e9, 2),
+                "kernel_gbs": round(r["n_owned"] / (r["kernel_ms"] * 1e-3) / 1e9, 2),
+                "matches_per_step": r["matches"], "kernel_variant": r["info"]["variant"]}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(res["ppath"], res["kind"], para)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,229 @@
+/*
+ * include/pfac.h -- C-ABI of the MI355X-native PFAC matcher.
+ *
+ * Two shared libraries implement it:
+ *   libpfac_host.so  (plain C, no GPU)  : pattern file -> PHF-compressed state-transition table
+ *   libpfac_hip.so   (HIP, gfx950)      : device contexts, table upload, the scan kernel, records
+ *
+ * Every entry point below names the reference interface it replaces
+ * (paths relative to mickeyjoe666/PHFPFAC regex_GPU_PHF/).  The reference has
+ * no FFI: main.cc calls three C++-linkage functions (main.cc:35-37) and
+ * #includes its table builder (main.cc:5-6).  A maintainer switches to this
+ * library by replacing those call sites; see INTEGRATION.md.
+ *
+ * Conventions: plain pointers and integers only; every function returns 0 on
+ * success or a negative pfac_status; nothing calls exit() (the reference exits
+ * on every error, e.g. master_kernel.cu:240-244).  No function falls back to
+ * a CPU implementation: without a usable GPU the HIP library reports
+ * PFAC_E_NO_DEVICE / PFAC_E_HIP.
+ */
+#ifndef PFAC_H
+#define PFAC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PFAC_OK = 0,
+    PFAC_E_ARG = -1,        /* bad argument (NULL, misaligned pointer, width not a power of two <= 4096, ...) */
+    PFAC_E_IO = -2,         /* cannot open / read a file */
+    PFAC_E_PATTERN = -3,    /* pattern file violates the reader's rules (length >= 1024, empty line, no trailing '\n') */
+    PFAC_E_NOMEM = -4,
+    PFAC_E_NO_DEVICE = -5,  /* no HIP device / bad device index */
+    PFAC_E_HIP = -6,        /* a HIP runtime call failed; see pfac_last_error() */
+    PFAC_E_STATE = -7,      /* call order violated (scan before table upload, ...) */
+    PFAC_E_OVERFLOW = -8,   /* more matches than the record buffer holds (count is still exact) */
+    PFAC_E_INTERNAL = -9    /* kernel reported an internal fault (look-back timeout) */
+} pfac_status;
+
+/* ------------------------------------------------------------------ */
+/* Host side (libpfac_host.so): the CreateTable/ + PHF/ path.          */
+
+/*
+ * The PHF-compressed transition table in the reference's own terms
+ * (struct thread_data, main.cc:19-32 / master_kernel.cu:15-28):
+ *   s0[256]          root row  PFAC[initial_state][*]            (main.cc:200)
+ *   r[max_row]       row displacement, may be negative, -1 empty (phf.c:67,197)
+ *   HT[ht_size]      owning row of each slot, -1 free            (phf.c:211)
+ *   val[ht_size]     next state of each slot                     (phf.c:216)
+ *   idmap[num_final] final state -> pattern id (1-based line no) (create_table_reorder.c:318)
+ * lookup(state, ch): key=(state<<8)+ch; row=key>>width_bit; col=key&(width-1);
+ *   idx=r[row]+col; 0<=idx<ht_size && HT[idx]==row ? val[idx] : -1   (master_kernel.cu:52-63)
+ * States: finals are 0..num_final-1 (index in the sorted pattern list), the
+ * root is num_final+1, internal states follow (create_table_reorder.c:287-292).
+ * Unlike the reference, ONE automaton covers the whole pattern file: the
+ * 4*streamnum pattern chunks (create_table_reorder.c:217) are not needed
+ * because the input, not the pattern set, is what gets sharded.
+ */
+typedef struct pfac_table {
+    int32_t width;          /* power of two, 1 <= width <= 4096 (phf.c:8,161) */
+    int32_t width_bit;      /* log2(width) (master_kernel.cu:397-398) */
+    int32_t n_patterns;     /* lines in the pattern file */
+    int32_t num_final;      /* == n_patterns (duplicates keep their own, unreachable, final state) */
+    int32_t state_num;
+    int32_t max_pat_len;
+    int32_t max_row;        /* entries in r   = (state_num*256)/width + 1 (master_kernel.cu:212) */
+    int32_t ht_size;        /* entries in HT and val */
+    int32_t n_keys;         /* transitions stored */
+    int32_t *s0;
+    int32_t *r;
+    int32_t *HT;
+    int32_t *val;
+    int32_t *idmap;
+} pfac_table;
+
+/* Replaces create_PFAC_table_reorder() + FFDM() (main.cc:108,125):
+ * read_pattern (create_table_reorder.c:53), sort (comp_pat :21), trie
+ * (patternsToPFAC :277) and the row-displacement perfect hash (phf.c:151),
+ * in near-linear time and without the 4 GiB-per-chunk preallocation. */
+int pfac_table_build_file(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len);
+/* Same, from a memory image of a pattern file. */
+int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len);
+void pfac_table_free(pfac_table *t);
+
+/* The device lookup evaluated on the host (property tests; never used on the scan path). */
+int32_t pfac_table_lookup(const pfac_table *t, int32_t state, int32_t ch);
+
+/* Flat int32 image of a table: what gets uploaded, and what RCCL broadcasts
+ * between ranks.  Layout: 16-word header {magic, version, width, width_bit,
+ * n_patterns, num_final, state_num, max_pat_len, max_row, ht_size, n_keys,
+ * 0...} then s0[256], r[max_row], HT[ht_size], val[ht_size], idmap[num_final]. */
+#define PFAC_BLOB_MAGIC 0x50464143 /* "PFAC" */
+#define PFAC_BLOB_VERSION 1
+#define PFAC_BLOB_HEADER_WORDS 16
+size_t pfac_table_blob_words(const pfac_table *t);
+int pfac_table_to_blob(const pfac_table *t, int32_t *blob, size_t n_words);
+int pfac_table_from_blob(const int32_t *blob, size_t n_words, pfac_table **out);
+/* Wrap arrays produced by the reference's own FFDM() (main.cc:72-76,125) so a
+ * reference build can feed this library without rebuilding its tables. */
+int pfac_table_from_reference_arrays(const int32_t *s0, const int32_t *r, const int32_t *HT, const int32_t *val,
+                                     const int32_t *idmap, int32_t width, int32_t state_num, int32_t num_final,
+                                     int32_t ht_size, int32_t max_pat_len, pfac_table **out);
+
+/* Text emitter: replaces main.cc:335-350.  One line per record,
+ * "At position %4d, match pattern %d\n" with pos = base + rec.pos and
+ * pattern = idmap[rec.state].  Appends to an open FILE* (void* to keep stdio
+ * out of the ABI); returns bytes written (>= 0) or a negative status. */
+typedef struct pfac_record {
+    uint32_t pos;       /* start offset, relative to the first byte of the scanned range */
+    uint32_t state;     /* final state reached (== index into idmap) */
+} pfac_record;
+int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap);
+
+/* ------------------------------------------------------------------ */
+/* Device side (libpfac_hip.so): the master_kernel.cu path.            */
+
+typedef struct pfac_ctx pfac_ctx;   /* one per GPU; holds what d_input_string/d_r/d_hash_table/
+                                       d_match_result/d_val_table/d_s0Table held (main.cc:99-104) */
+
+int pfac_device_count(int *n);                                       /* cudaGetDeviceCount, main.cc:50 */
+/* Replaces cudaSetDevice + cudaStreamCreate (main.cc:183,209) and the
+ * allocation half of GPU_Malloc_Memory (master_kernel.cu:188-257).
+ * n_streams >= 1 independent pipeline slots ("streams per GPU", argv[2]). */
+int pfac_ctx_create(int device, int n_streams, pfac_ctx **out);
+void pfac_ctx_destroy(pfac_ctx *ctx);                                /* GPU_Free_memory, master_kernel.cu:457-524 */
+const char *pfac_last_error(const pfac_ctx *ctx);                    /* ctx may be NULL: last error of the calling thread */
+
+/* Table upload: the H2D copies of r/HT/s0/val and the texture binds
+ * (master_kernel.cu:302-320,365-383).  blob is a pfac_table_to_blob image in
+ * host memory; the _device variant takes an image already in this GPU's
+ * memory (e.g. the receive buffer of an RCCL broadcast) and uses `stream_handle`
+ * (a hipStream_t, may be NULL) for ordering. */
+int pfac_table_upload(pfac_ctx *ctx, const int32_t *blob, size_t n_words);
+int pfac_table_upload_device(pfac_ctx *ctx, const void *d_blob, size_t n_words, void *stream_handle);
+
+/* Pinned host memory, replaces cudaHostAlloc(..., cudaHostAllocPortable) (main.cc:147,161). */
+int pfac_host_alloc(void **p, size_t n_bytes);
+void pfac_host_free(void *p);
+
+/* Per-slot device buffers owned by the context.  Input capacity is rounded up
+ * so the kernel's tile loads stay in bounds (master_kernel.cu:217 pads by
+ * one tile + 512 B for the same reason). */
+int pfac_slot_reserve(pfac_ctx *ctx, int slot, uint64_t input_bytes, uint64_t record_capacity);
+void *pfac_slot_input(pfac_ctx *ctx, int slot);          /* device pointer, 256-B aligned */
+pfac_record *pfac_slot_records(pfac_ctx *ctx, int slot); /* device pointer */
+void *pfac_slot_stream(pfac_ctx *ctx, int slot);         /* the slot's hipStream_t */
+/* Use an EXTERNAL stream (e.g. torch's current stream) for a slot; NULL restores the slot's own. */
+int pfac_slot_set_stream(pfac_ctx *ctx, int slot, void *stream_handle);
+
+/* Async H2D of input bytes into the slot's input buffer at dst_offset
+ * (cudaMemcpy H2D, master_kernel.cu:359, made asynchronous on the slot's stream). */
+int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, uint64_t dst_offset);
+
+/*
+ * The scan: replaces the kernel launch of GPU_TraceTable (master_kernel.cu:396-423).
+ *   d_input   device pointer, 16-B aligned; NULL = the slot's own input buffer
+ *   n_owned   start offsets [0, n_owned) are matched and reported   (<= 2^32)
+ *   n_avail   bytes readable from d_input, n_owned <= n_avail; walks that
+ *             start in the owned range may read up to n_avail (the halo of
+ *             max_pat_len-1 bytes that belongs to the next shard) and never beyond
+ *   d_records device pointer for the ordered compact records, NULL = the slot's
+ *   capacity  records that fit; the count is exact even when it overflows
+ * Records come out sorted by (pos, pattern length) == the reference's output
+ * order (main.cc:341-349).  Asynchronous on the slot's stream.
+ */
+int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_owned, uint64_t n_avail,
+                    pfac_record *d_records, uint64_t capacity);
+/* Wait for the slot and fetch the exact number of matches.  Returns
+ * PFAC_E_OVERFLOW (with *n_matches set) when capacity was exceeded. */
+int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches);
+/* Kernel time of the slot's last scan (hipEvent pair around the launch, the
+ * analogue of "2. MASTER: The elapsed time is %f ms", master_kernel.cu:400-421). */
+int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms);
+/* D2H of records [first, first+n) (the compact replacement of the dense
+ * cudaMemcpy D2H, master_kernel.cu:428).  Asynchronous; pfac_slot_sync() completes it. */
+int pfac_records_d2h(pfac_ctx *ctx, int slot, const pfac_record *d_records, pfac_record *host, uint64_t first, uint64_t n);
+int pfac_slot_sync(pfac_ctx *ctx, int slot);
+
+/* Order-independent 64-bit checksum of n records (sum over records of
+ * mix(base+pos, idmap[state])), computed on the GPU; used for full-size
+ * parity checks where materialising the text is not practical. */
+int pfac_records_checksum(pfac_ctx *ctx, int slot, const pfac_record *d_records, uint64_t n, uint64_t base,
+                          uint64_t *checksum);
+
+/* Synthetic input generators, written straight into device memory (the
+ * reference built big inputs by tiling a small text, creatbiginput.sh:2-5).
+ *   tiled : byte i = pattern[(phase + i) % period]
+ *   random: byte i = byte (i&7) of splitmix64(seed + (i>>3))  (counter based) */
+int pfac_fill_tiled(pfac_ctx *ctx, int slot, void *d_dst, uint64_t n, const void *host_pattern, uint32_t period,
+                    uint64_t phase);
+int pfac_fill_random(pfac_ctx *ctx, int slot, void *d_dst, uint64_t n, uint64_t seed);
+
+/* Kernel introspection for bench/DESIGN: variant chosen for the uploaded table
+ * (0 = tables in LDS, 1 = tables via L2), tile bytes, grid size, LDS bytes. */
+int pfac_scan_info(pfac_ctx *ctx, int *variant, int *tile_bytes, int *grid_blocks, int *lds_bytes);
+
+/* ------------------------------------------------------------------ */
+/* Drop-in shaped like the reference seam (main.cc:19-37).             */
+
+/* Field-for-field struct thread_data (main.cc:19-32). */
+typedef struct pfac_thread_data {
+    unsigned char *input_string;
+    int input_size;
+    int state_num;
+    int final_state_num;
+    unsigned int *match_result;     /* dense: input_size * max_pat_len slots, 0xFFFFFFFF = empty */
+    int HTSize;
+    int width;
+    int *s0Table;
+    int max_pat_len;
+    int *r;
+    int *HT;
+    int *val;
+} pfac_thread_data;
+
+/* GPU_Malloc_Memory + GPU_TraceTable + GPU_Free_memory in one synchronous
+ * call (master_kernel.cu:188-524): uploads dataset's tables and input to
+ * `device`, scans, and fills dataset->match_result in the reference's dense
+ * layout (slot j of position i = j-th final state reached from i, rest
+ * 0xFFFFFFFF) so that main.cc:304-350 can run unchanged on it. */
+int pfac_trace_table_compat(const pfac_thread_data *dataset, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFAC_H */

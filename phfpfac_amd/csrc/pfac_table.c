@@ -1,0 +1,440 @@
+/*
+ * pfac_table.c -- host-side C: pattern file -> PHF-compressed PFAC transition table.
+ *
+ * Product code (libpfac_host.so).  Same observable semantics as the
+ * reference's CreateTable/ + PHF/ path, built differently:
+ *
+ *   reader   create_table_reorder.c:53-122 (read_pattern): '\n'-separated raw
+ *            bytes, id = 1-based line number, 1 <= length < 1023+1, file ends in
+ *            '\n'.  Violations are reported as PFAC_E_PATTERN instead of exit(1)
+ *            (or, for a missing final newline / empty line, instead of the
+ *            reference's undefined behaviour).
+ *   sort     create_table_reorder.c:21-45,116 (comp_pat + qsort): memcmp on the
+ *            common prefix, shorter first; STABLE, so among identical lines the
+ *            later one wins its final state (create_table_reorder.c:366).
+ *   trie     create_table_reorder.c:277-378 (patternsToPFAC): identical state
+ *            numbering (finals 0..n-1 = sorted index, n unused, root n+1,
+ *            internals from n+2 in creation order), but built from the sorted
+ *            list with an LCP stack into an edge list -- O(total bytes), no
+ *            dense int[state][256] rows, no 4 GiB preallocation
+ *            (create_table_reorder.c:10,306-311).
+ *   PHF      phf.c:151-291 (FFDM): the same row-displacement perfect hash with
+ *            the same lookup contract (r may be negative, -1 = empty row; HT
+ *            holds the owning row; val the next state), rows placed in
+ *            descending fullness, first fit.  The reference's O(rows^2)
+ *            exchange sort (phf.c:126-139) is replaced by a counting sort and
+ *            the first-fit scan keeps a first-free cursor; the resulting LAYOUT
+ *            therefore differs from the reference's, the lookup function does
+ *            not (tests/test_table.py checks every (state, byte) cell).
+ */
+#include "pfac.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PFAC_MAX_PATTERN_LEN 1023   /* str[1024] with the '\n' (create_table_reorder.c:55,74) */
+#define PFAC_COL_MAX 4096           /* phf.c:8 */
+
+typedef struct {
+    int32_t id;
+    int32_t len;
+    const unsigned char *pat;       /* points into the file image */
+} pat_t;
+
+typedef struct {
+    int32_t from;
+    int32_t ch;
+    int32_t to;
+} edge_t;
+
+static void set_err(char *err, size_t n, const char *msg, long a) {
+    if (err && n) snprintf(err, n, msg, a);
+}
+
+static int cmp_pat(const pat_t *a, const pat_t *b) {
+    int32_t m = a->len < b->len ? a->len : b->len;
+    int r = memcmp(a->pat, b->pat, (size_t)m);
+    if (r) return r;
+    return (a->len > b->len) - (a->len < b->len);
+}
+
+static void merge_sort(pat_t *a, pat_t *tmp, size_t n) {
+    if (n < 2) return;
+    if (n <= 8) {                       /* stable insertion sort for short runs */
+        for (size_t i = 1; i < n; i++) {
+            pat_t x = a[i];
+            size_t j = i;
+            while (j > 0 && cmp_pat(&x, &a[j - 1]) < 0) { a[j] = a[j - 1]; j--; }
+            a[j] = x;
+        }
+        return;
+    }
+    size_t h = n / 2;
+    merge_sort(a, tmp, h);
+    merge_sort(a + h, tmp, n - h);
+    if (cmp_pat(&a[h], &a[h - 1]) >= 0) return;
+    size_t i = 0, j = h, k = 0;
+    while (i < h && j < n) tmp[k++] = (cmp_pat(&a[j], &a[i]) < 0) ? a[j++] : a[i++];
+    while (i < h) tmp[k++] = a[i++];
+    /* if the left run ran out first, the tail a[j..n) is already in place (k == j) */
+    memcpy(a, tmp, k * sizeof(pat_t));
+}
+
+static int edge_key_cmp(const void *x, const void *y) {
+    const edge_t *a = (const edge_t *)x, *b = (const edge_t *)y;
+    if (a->from != b->from) return (a->from > b->from) - (a->from < b->from);
+    return a->ch - b->ch;
+}
+
+static int is_pow2(int w) { return w > 0 && (w & (w - 1)) == 0; }
+
+void pfac_table_free(pfac_table *t) {
+    if (!t) return;
+    free(t->s0); free(t->r); free(t->HT); free(t->val); free(t->idmap);
+    free(t);
+}
+
+/* Row-displacement perfect hash over the edge list (sorted by key). */
+static int build_phf(pfac_table *t, const edge_t *edges, int32_t n_edges, char *err, size_t err_len) {
+    const int32_t width = t->width;
+    const int wbit = t->width_bit;
+    const int32_t max_row = (int32_t)(((int64_t)t->state_num * 256) / width) + 1;
+    t->max_row = max_row;
+    t->n_keys = n_edges;
+    int32_t *row_cnt = (int32_t *)calloc((size_t)max_row + 1, sizeof(int32_t));
+    int32_t *row_start = (int32_t *)malloc(((size_t)max_row + 1) * sizeof(int32_t));
+    int32_t *order = (int32_t *)malloc((size_t)max_row * sizeof(int32_t));
+    int32_t *bucket = (int32_t *)calloc((size_t)width + 2, sizeof(int32_t));
+    t->r = (int32_t *)malloc((size_t)max_row * sizeof(int32_t));
+    if (!row_cnt || !row_start || !order || !bucket || !t->r) { set_err(err, err_len, "out of memory (%ld rows)", max_row); return PFAC_E_NOMEM; }
+    memset(t->r, 0xFF, (size_t)max_row * sizeof(int32_t));
+    for (int32_t e = 0; e < n_edges; e++) {
+        int64_t key = ((int64_t)edges[e].from << 8) + edges[e].ch;
+        row_cnt[key >> wbit]++;
+    }
+    row_start[0] = 0;
+    for (int32_t i = 0; i < max_row; i++) row_start[i + 1] = row_start[i] + row_cnt[i];
+    /* counting sort of rows by fullness, descending; ties by row number ascending */
+    for (int32_t i = 0; i < max_row; i++) bucket[row_cnt[i]]++;
+    int32_t acc = 0;
+    for (int32_t c = width; c >= 0; c--) { int32_t n = bucket[c]; bucket[c] = acc; acc += n; }
+    for (int32_t i = 0; i < max_row; i++) order[bucket[row_cnt[i]]++] = i;
+
+    int64_t cap = (int64_t)n_edges + 2 * (int64_t)width + 64;
+    int32_t *HT = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+    int32_t *val = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+    if (!HT || !val) { set_err(err, err_len, "out of memory (%ld slots)", (long)cap); return PFAC_E_NOMEM; }
+    memset(HT, 0xFF, (size_t)cap * sizeof(int32_t));
+    memset(val, 0xFF, (size_t)cap * sizeof(int32_t));
+    /* nxt[i] = a free slot >= i (union-find with path halving); lets the first-fit
+     * scan visit only offsets whose first column lands on a free slot */
+    int32_t *nxt = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+    if (!nxt) { set_err(err, err_len, "out of memory (%ld slots)", (long)cap); return PFAC_E_NOMEM; }
+    for (int64_t i = 0; i < cap; i++) nxt[i] = (int32_t)i;
+    int64_t max_used = -1, multi_cursor = 0;
+    /* small automata: exact first fit (cursor never moves); large ones: bounded look-back */
+    const int64_t lookback = n_edges <= 65536 ? INT64_MAX / 2 : 4 * (int64_t)width;
+    const int32_t cmask = width - 1;
+    for (int32_t o = 0; o < max_row; o++) {
+        const int32_t row = order[o];
+        const int32_t cnt = row_cnt[row];
+        if (cnt == 0) break;
+        const edge_t *re = edges + row_start[row];
+        const int32_t col0 = (int32_t)((((int64_t)re[0].from << 8) + re[0].ch) & cmask);
+        /* the reference tries every offset from -col0 upwards (phf.c:188); an offset
+         * can only succeed if slot offset+col0 is free, so walk the free slots */
+        /* multi-key rows resume a little before where the previous one fitted: the
+         * slots further back are holes that rows of this fullness already failed on
+         * (keeps the build near-linear; single-key rows still fill every hole) */
+        int64_t p = cnt > 1 ? multi_cursor : 0, offset;
+        for (;;) {
+            while (nxt[p] != p) { nxt[p] = nxt[nxt[p]]; p = nxt[p]; }   /* find */
+            offset = p - col0;
+            if (offset + width + 1 >= cap) {
+                int64_t ncap = cap * 2;
+                HT = (int32_t *)realloc(HT, (size_t)ncap * sizeof(int32_t));
+                val = (int32_t *)realloc(val, (size_t)ncap * sizeof(int32_t));
+                nxt = (int32_t *)realloc(nxt, (size_t)ncap * sizeof(int32_t));
+                if (!HT || !val || !nxt) { set_err(err, err_len, "out of memory (%ld slots)", (long)ncap); return PFAC_E_NOMEM; }
+                memset(HT + cap, 0xFF, (size_t)(ncap - cap) * sizeof(int32_t));
+                memset(val + cap, 0xFF, (size_t)(ncap - cap) * sizeof(int32_t));
+                for (int64_t i = cap; i < ncap; i++) nxt[i] = (int32_t)i;
+                cap = ncap;
+            }
+            int32_t i;
+            for (i = 1; i < cnt; i++) {
+                int32_t col = (int32_t)((((int64_t)re[i].from << 8) + re[i].ch) & cmask);
+                if (HT[offset + col] != -1) break;
+            }
+            if (i == cnt) break;
+            p++;
+        }
+        if (offset > INT32_MAX - width) { set_err(err, err_len, "hash table too large (%ld)", (long)offset); return PFAC_E_NOMEM; }
+        t->r[row] = (int32_t)offset;
+        if (cnt > 1 && p - lookback > multi_cursor) multi_cursor = p - lookback;
+        for (int32_t i = 0; i < cnt; i++) {
+            int32_t col = (int32_t)((((int64_t)re[i].from << 8) + re[i].ch) & cmask);
+            HT[offset + col] = row;
+            val[offset + col] = re[i].to;
+            nxt[offset + col] = (int32_t)(offset + col + 1);
+            if (offset + col > max_used) max_used = offset + col;
+        }
+    }
+    free(nxt);
+    t->ht_size = (int32_t)(max_used + 1);
+    if (t->ht_size < 1) t->ht_size = 1;     /* keep the arrays non-empty */
+    t->HT = (int32_t *)realloc(HT, (size_t)t->ht_size * sizeof(int32_t));
+    t->val = (int32_t *)realloc(val, (size_t)t->ht_size * sizeof(int32_t));
+    free(row_cnt); free(row_start); free(order); free(bucket);
+    return PFAC_OK;
+}
+
+int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len) {
+    if (!patterns || !out) { set_err(err, err_len, "null argument%ld", 0); return PFAC_E_ARG; }
+    *out = NULL;
+    if (!is_pow2(width) || width > PFAC_COL_MAX) {
+        set_err(err, err_len, "PHF width %ld must be a power of two <= 4096", width); return PFAC_E_ARG;
+    }
+    const unsigned char *buf = (const unsigned char *)patterns;
+    if (n_bytes == 0 || buf[n_bytes - 1] != '\n') {
+        set_err(err, err_len, "pattern file must end with a newline (%ld bytes)", (long)n_bytes); return PFAC_E_PATTERN;
+    }
+    /* ---- reader ---- */
+    size_t n_lines = 0;
+    for (size_t i = 0; i < n_bytes; i++) n_lines += (buf[i] == '\n');
+    if (n_lines > (size_t)INT32_MAX / 2) { set_err(err, err_len, "too many patterns (%ld)", (long)n_lines); return PFAC_E_PATTERN; }
+    pat_t *pats = (pat_t *)malloc(n_lines * sizeof(pat_t));
+    pat_t *tmp = (pat_t *)malloc(n_lines * sizeof(pat_t));
+    if (!pats || !tmp) { free(pats); free(tmp); set_err(err, err_len, "out of memory (%ld patterns)", (long)n_lines); return PFAC_E_NOMEM; }
+    size_t start = 0, n = 0;
+    int32_t max_len = 0;
+    for (size_t i = 0; i < n_bytes; i++) {
+        if (buf[i] != '\n') continue;
+        size_t len = i - start;
+        if (len == 0) { free(pats); free(tmp); set_err(err, err_len, "pattern %ld is empty", (long)n + 1); return PFAC_E_PATTERN; }
+        if (len > PFAC_MAX_PATTERN_LEN) { free(pats); free(tmp); set_err(err, err_len, "Pattern %ld length over 1024.", (long)n + 1); return PFAC_E_PATTERN; }
+        pats[n].id = (int32_t)(n + 1);
+        pats[n].len = (int32_t)len;
+        pats[n].pat = buf + start;
+        if ((int32_t)len > max_len) max_len = (int32_t)len;
+        n++;
+        start = i + 1;
+    }
+    merge_sort(pats, tmp, n);
+    free(tmp);
+
+    /* ---- trie as an edge list (LCP stack over the sorted list) ---- */
+    size_t total_bytes = n_bytes - n_lines;
+    if ((int64_t)n + 2 + (int64_t)total_bytes > INT32_MAX / 256) {
+        /* keys are (state<<8)+ch in int32 on the device (master_kernel.cu:52) */
+        free(pats); set_err(err, err_len, "automaton too large (%ld pattern bytes)", (long)total_bytes); return PFAC_E_PATTERN;
+    }
+    edge_t *edges = (edge_t *)malloc((total_bytes + 1) * sizeof(edge_t));
+    int32_t *path = (int32_t *)malloc((PFAC_MAX_PATTERN_LEN + 1) * sizeof(int32_t));
+    int32_t *path_edge = (int32_t *)malloc((PFAC_MAX_PATTERN_LEN + 1) * sizeof(int32_t));
+    pfac_table *t = (pfac_table *)calloc(1, sizeof *t);
+    int32_t *idmap = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    if (!edges || !path || !path_edge || !t || !idmap) {
+        free(pats); free(edges); free(path); free(path_edge); free(t); free(idmap);
+        set_err(err, err_len, "out of memory (%ld bytes)", (long)total_bytes); return PFAC_E_NOMEM;
+    }
+    const int32_t root = (int32_t)n + 1;
+    int32_t state_count = root + 1;
+    int32_t n_edges = 0;
+    const pat_t *prev = NULL;
+    for (size_t i = 0; i < n; i++) {
+        const pat_t *cur = &pats[i];
+        idmap[i] = cur->id;
+        int32_t l = 0;
+        if (prev) {
+            int32_t m = prev->len < cur->len ? prev->len : cur->len;
+            while (l < m && prev->pat[l] == cur->pat[l]) l++;
+        }
+        if (prev && l == cur->len) {
+            /* identical to the previous line: the edge into its final state is
+             * re-pointed at the later pattern (create_table_reorder.c:366) */
+            edges[path_edge[l - 1]].to = (int32_t)i;
+            path[l - 1] = (int32_t)i;
+            prev = cur;
+            continue;
+        }
+        /* path[d] = state after d+1 bytes of prev; the first l are shared */
+        int32_t state = l ? path[l - 1] : root;
+        for (int32_t j = l; j < cur->len; j++) {
+            int32_t to = (j == cur->len - 1) ? (int32_t)i : state_count++;
+            edges[n_edges].from = state;
+            edges[n_edges].ch = cur->pat[j];
+            edges[n_edges].to = to;
+            path[j] = to;
+            path_edge[j] = n_edges;
+            n_edges++;
+            state = to;
+        }
+        prev = cur;
+    }
+    free(path); free(path_edge); free(pats);
+
+    t->width = width;
+    for (t->width_bit = 0; (width >> t->width_bit) != 1; t->width_bit++) ;
+    t->n_patterns = (int32_t)n;
+    t->num_final = (int32_t)n;
+    t->state_num = state_count;
+    t->max_pat_len = max_len;
+    t->idmap = idmap;
+    t->s0 = (int32_t *)malloc(256 * sizeof(int32_t));
+    if (!t->s0) { free(edges); pfac_table_free(t); return PFAC_E_NOMEM; }
+    memset(t->s0, 0xFF, 256 * sizeof(int32_t));
+    qsort(edges, (size_t)n_edges, sizeof(edge_t), edge_key_cmp);
+    for (int32_t e = 0; e < n_edges; e++)
+        if (edges[e].from == root) t->s0[edges[e].ch] = edges[e].to;
+    int rc = build_phf(t, edges, n_edges, err, err_len);
+    free(edges);
+    if (rc) { pfac_table_free(t); return rc; }
+    *out = t;
+    return PFAC_OK;
+}
+
+int pfac_table_build_file(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len) {
+    if (!pattern_file || !out) return PFAC_E_ARG;
+    FILE *f = fopen(pattern_file, "rb");
+    if (!f) { if (err && err_len) snprintf(err, err_len, "cannot open pattern file %s", pattern_file); return PFAC_E_IO; }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    rewind(f);
+    unsigned char *buf = (unsigned char *)malloc(sz > 0 ? (size_t)sz : 1);
+    if (!buf) { fclose(f); return PFAC_E_NOMEM; }
+    if (sz > 0 && fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); return PFAC_E_IO; }
+    fclose(f);
+    int rc = pfac_table_build_mem(buf, sz > 0 ? (size_t)sz : 0, width, out, err, err_len);
+    free(buf);
+    return rc;
+}
+
+int32_t pfac_table_lookup(const pfac_table *t, int32_t state, int32_t ch) {
+    int32_t key = (state << 8) + ch;
+    int32_t row = key >> t->width_bit;
+    int32_t col = key & (t->width - 1);
+    if (row < 0 || row >= t->max_row) return -1;
+    int32_t idx = t->r[row] + col;
+    if (idx < 0 || idx >= t->ht_size) return -1;
+    return t->HT[idx] == row ? t->val[idx] : -1;
+}
+
+/* ---- flat image ---- */
+size_t pfac_table_blob_words(const pfac_table *t) {
+    return (size_t)PFAC_BLOB_HEADER_WORDS + 256 + (size_t)t->max_row + 2 * (size_t)t->ht_size + (size_t)t->num_final;
+}
+
+int pfac_table_to_blob(const pfac_table *t, int32_t *blob, size_t n_words) {
+    if (!t || !blob || n_words < pfac_table_blob_words(t)) return PFAC_E_ARG;
+    memset(blob, 0, PFAC_BLOB_HEADER_WORDS * sizeof(int32_t));
+    blob[0] = PFAC_BLOB_MAGIC; blob[1] = PFAC_BLOB_VERSION;
+    blob[2] = t->width; blob[3] = t->width_bit; blob[4] = t->n_patterns; blob[5] = t->num_final;
+    blob[6] = t->state_num; blob[7] = t->max_pat_len; blob[8] = t->max_row; blob[9] = t->ht_size;
+    blob[10] = t->n_keys;
+    int32_t *p = blob + PFAC_BLOB_HEADER_WORDS;
+    memcpy(p, t->s0, 256 * sizeof(int32_t)); p += 256;
+    memcpy(p, t->r, (size_t)t->max_row * sizeof(int32_t)); p += t->max_row;
+    memcpy(p, t->HT, (size_t)t->ht_size * sizeof(int32_t)); p += t->ht_size;
+    memcpy(p, t->val, (size_t)t->ht_size * sizeof(int32_t)); p += t->ht_size;
+    memcpy(p, t->idmap, (size_t)t->num_final * sizeof(int32_t));
+    return PFAC_OK;
+}
+
+static int32_t *dup_words(const int32_t *src, size_t n) {
+    int32_t *d = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    if (d && n) memcpy(d, src, n * sizeof(int32_t));
+    return d;
+}
+
+int pfac_table_from_blob(const int32_t *blob, size_t n_words, pfac_table **out) {
+    if (!blob || !out || n_words < PFAC_BLOB_HEADER_WORDS) return PFAC_E_ARG;
+    if (blob[0] != PFAC_BLOB_MAGIC || blob[1] != PFAC_BLOB_VERSION) return PFAC_E_ARG;
+    pfac_table *t = (pfac_table *)calloc(1, sizeof *t);
+    if (!t) return PFAC_E_NOMEM;
+    t->width = blob[2]; t->width_bit = blob[3]; t->n_patterns = blob[4]; t->num_final = blob[5];
+    t->state_num = blob[6]; t->max_pat_len = blob[7]; t->max_row = blob[8]; t->ht_size = blob[9];
+    t->n_keys = blob[10];
+    if (!is_pow2(t->width) || t->width > PFAC_COL_MAX || (1 << t->width_bit) != t->width || t->max_row < 1 ||
+        t->ht_size < 1 || t->num_final < 0 || t->state_num < t->num_final + 2 || pfac_table_blob_words(t) > n_words) {
+        free(t); return PFAC_E_ARG;
+    }
+    const int32_t *p = blob + PFAC_BLOB_HEADER_WORDS;
+    t->s0 = dup_words(p, 256); p += 256;
+    t->r = dup_words(p, (size_t)t->max_row); p += t->max_row;
+    t->HT = dup_words(p, (size_t)t->ht_size); p += t->ht_size;
+    t->val = dup_words(p, (size_t)t->ht_size); p += t->ht_size;
+    t->idmap = dup_words(p, (size_t)t->num_final);
+    if (!t->s0 || !t->r || !t->HT || !t->val || !t->idmap) { pfac_table_free(t); return PFAC_E_NOMEM; }
+    *out = t;
+    return PFAC_OK;
+}
+
+int pfac_table_from_reference_arrays(const int32_t *s0, const int32_t *r, const int32_t *HT, const int32_t *val,
+                                     const int32_t *idmap, int32_t width, int32_t state_num, int32_t num_final,
+                                     int32_t ht_size, int32_t max_pat_len, pfac_table **out) {
+    if (!s0 || !r || !HT || !val || !out || !is_pow2(width) || width > PFAC_COL_MAX || ht_size < 0 ||
+        num_final < 0 || state_num < num_final + 2)
+        return PFAC_E_ARG;
+    pfac_table *t = (pfac_table *)calloc(1, sizeof *t);
+    if (!t) return PFAC_E_NOMEM;
+    t->width = width;
+    for (t->width_bit = 0; (width >> t->width_bit) != 1; t->width_bit++) ;
+    t->n_patterns = t->num_final = num_final;
+    t->state_num = state_num;
+    t->max_pat_len = max_pat_len;
+    t->max_row = (int32_t)(((int64_t)state_num * 256) / width) + 1;     /* master_kernel.cu:212 */
+    t->ht_size = ht_size > 0 ? ht_size : 1;
+    t->s0 = dup_words(s0, 256);
+    t->r = dup_words(r, (size_t)t->max_row);
+    if (ht_size > 0) { t->HT = dup_words(HT, (size_t)ht_size); t->val = dup_words(val, (size_t)ht_size); }
+    else {
+        t->HT = (int32_t *)malloc(sizeof(int32_t)); t->val = (int32_t *)malloc(sizeof(int32_t));
+        if (t->HT) t->HT[0] = -1;
+        if (t->val) t->val[0] = -1;
+    }
+    t->idmap = (int32_t *)malloc((num_final ? (size_t)num_final : 1) * sizeof(int32_t));
+    if (!t->s0 || !t->r || !t->HT || !t->val || !t->idmap) { pfac_table_free(t); return PFAC_E_NOMEM; }
+    for (int32_t i = 0; i < num_final; i++) t->idmap[i] = idmap ? idmap[i] : i;
+    for (int32_t i = 0; i < t->ht_size; i++) t->n_keys += (t->HT[i] >= 0);
+    *out = t;
+    return PFAC_OK;
+}
+
+/* ---- text emitter (main.cc:335-350) ---- */
+static inline char *put_uint(char *p, uint64_t v, int min_width) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    for (int i = n; i < min_width; i++) *p++ = ' ';
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap) {
+    if (!file || (!rec && n) || !idmap) return PFAC_E_ARG;
+    FILE *f = (FILE *)file;
+    enum { CHUNK = 1 << 16, LINE_MAX_BYTES = 64 };
+    char *buf = (char *)malloc((size_t)CHUNK * LINE_MAX_BYTES);
+    if (!buf) return PFAC_E_NOMEM;
+    int64_t total = 0;
+    for (uint64_t k0 = 0; k0 < n; k0 += CHUNK) {
+        uint64_t k1 = k0 + CHUNK < n ? k0 + CHUNK : n;
+        char *p = buf;
+        for (uint64_t k = k0; k < k1; k++) {
+            memcpy(p, "At position ", 12); p += 12;
+            p = put_uint(p, base + rec[k].pos, 4);                /* %4d */
+            memcpy(p, ", match pattern ", 16); p += 16;
+            int32_t id = idmap[rec[k].state];
+            if (id < 0) { *p++ = '-'; p = put_uint(p, (uint64_t)(-(int64_t)id), 1); }
+            else p = put_uint(p, (uint64_t)id, 1);                /* %d */
+            *p++ = '\n';
+        }
+        size_t len = (size_t)(p - buf);
+        if (fwrite(buf, 1, len, f) != len) { free(buf); return PFAC_E_IO; }
+        total += (int64_t)len;
+    }
+    free(buf);
+    return total;
+}

@@ -1,0 +1,135 @@
+"""Host-side table build: pattern file -> PHF-compressed PFAC transition table.
+
+Thin wrapper over ``libpfac_host.so`` (``csrc/pfac_table.c``), i.e. over the
+replacement of the reference's ``create_PFAC_table_reorder()`` + ``FFDM()``
+(main.cc:108,125).  All arithmetic happens in the C library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._ffi import CTable, PfacError, host_lib
+
+RECORD_DTYPE = np.dtype([("pos", np.uint32), ("state", np.uint32)])
+
+
+class PfacTable:
+    """One automaton over the whole pattern file, in the reference's table terms.
+
+    Attributes mirror ``struct thread_data`` (main.cc:19-32): ``s0`` (root row),
+    ``r``, ``HT``, ``val`` (the perfect hash), ``width``, ``ht_size`` (HTSize),
+    ``state_num``, ``num_final`` (final_state_num), ``max_pat_len``; ``idmap``
+    is ``patternIdMaps`` (final state -> 1-based pattern line number).
+    """
+
+    def __init__(self, ptr):
+        self._ptr = ptr
+        t = ptr.contents
+        for name in ("width", "width_bit", "n_patterns", "num_final", "state_num", "max_pat_len", "max_row",
+                     "ht_size", "n_keys"):
+            setattr(self, name, int(getattr(t, name)))
+        self.s0 = np.ctypeslib.as_array(t.s0, (256,))
+        self.r = np.ctypeslib.as_array(t.r, (self.max_row,))
+        self.HT = np.ctypeslib.as_array(t.HT, (self.ht_size,))
+        self.val = np.ctypeslib.as_array(t.val, (self.ht_size,))
+        self.idmap = np.ctypeslib.as_array(t.idmap, (max(self.num_final, 1),))[: self.num_final]
+
+    # -- construction -----------------------------------------------------
+    @classmethod
+    def from_file(cls, pattern_file: str, width: int = 256) -> "PfacTable":
+        L = host_lib()
+        ptr = C.POINTER(CTable)()
+        err = C.create_string_buffer(256)
+        rc = L.pfac_table_build_file(os.fsencode(pattern_file), int(width), C.byref(ptr), err, 256)
+        if rc:
+            raise PfacError(rc, err.value.decode(errors="replace"))
+        return cls(ptr)
+
+    @classmethod
+    def from_bytes(cls, patterns: bytes, width: int = 256) -> "PfacTable":
+        L = host_lib()
+        ptr = C.POINTER(CTable)()
+        err = C.create_string_buffer(256)
+        buf = C.create_string_buffer(patterns, len(patterns))
+        rc = L.pfac_table_build_mem(buf, len(patterns), int(width), C.byref(ptr), err, 256)
+        if rc:
+            raise PfacError(rc, err.value.decode(errors="replace"))
+        return cls(ptr)
+
+    @classmethod
+    def from_blob(cls, blob: np.ndarray) -> "PfacTable":
+        L = host_lib()
+        blob = np.ascontiguousarray(blob, dtype=np.int32)
+        ptr = C.POINTER(CTable)()
+        rc = L.pfac_table_from_blob(blob.ctypes.data, blob.size, C.byref(ptr))
+        if rc:
+            raise PfacError(rc, "bad table image")
+        return cls(ptr)
+
+    @classmethod
+    def from_reference_arrays(cls, s0, r, HT, val, idmap, width, state_num, num_final, ht_size, max_pat_len):
+        """Wrap arrays produced by the reference's own FFDM() (main.cc:72-76,125)."""
+        L = host_lib()
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (s0, r, HT, val, idmap)]
+        ptr = C.POINTER(CTable)()
+        rc = L.pfac_table_from_reference_arrays(*[a.ctypes.data for a in arrs], int(width), int(state_num),
+                                                int(num_final), int(ht_size), int(max_pat_len), C.byref(ptr))
+        if rc:
+            raise PfacError(rc, "bad reference arrays")
+        return cls(ptr)
+
+    # -- use --------------------------------------------------------------
+    def lookup(self, state: int, ch: int) -> int:
+        """The device lookup (master_kernel.cu:52-63) evaluated on the host."""
+        return int(host_lib().pfac_table_lookup(self._ptr, int(state), int(ch)))
+
+    def blob(self) -> np.ndarray:
+        """Flat int32 image (what gets uploaded / broadcast between ranks)."""
+        L = host_lib()
+        n = int(L.pfac_table_blob_words(self._ptr))
+        out = np.empty(n, dtype=np.int32)
+        rc = L.pfac_table_to_blob(self._ptr, out.ctypes.data, n)
+        if rc:
+            raise PfacError(rc, "pfac_table_to_blob")
+        return out
+
+    @property
+    def halo(self) -> int:
+        """Bytes a shard must be able to read past its owned range."""
+        return max(self.max_pat_len - 1, 0)
+
+    def pattern_ids(self, records: np.ndarray) -> np.ndarray:
+        return self.idmap[records["state"]]
+
+    def __del__(self):
+        ptr = getattr(self, "_ptr", None)
+        if ptr is not None:
+            try:
+                host_lib().pfac_table_free(ptr)
+            except Exception:
+                pass
+            self._ptr = None
+
+
+def emit_records(path_or_file, records: np.ndarray, idmap: np.ndarray, base: int = 0, append: bool = False) -> int:
+    """Write ``At position %4d, match pattern %d`` lines (main.cc:335-350).  Returns bytes written."""
+    L = host_lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+    idmap = np.ascontiguousarray(idmap, dtype=np.int32)
+    f = libc.fopen(os.fsencode(path_or_file), b"ab" if append else b"wb")
+    if not f:
+        raise PfacError(-2, f"cannot open {path_or_file}")
+    try:
+        n = L.pfac_emit_records(f, records.ctypes.data, records.size, int(base), idmap.ctypes.data)
+    finally:
+        libc.fclose(f)
+    if n < 0:
+        raise PfacError(int(n), "pfac_emit_records")
+    return int(n)

@@ -1,0 +1,284 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI of
+include/pfac.h, against (a) the committed golden outputs of the reference pipeline and (b) the CPU
+oracle on the same seeded inputs.  Everything here is integer/byte work: the bar is BIT-EXACT.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from orc import Oracle, match_checksum
+from phfpfac_amd import GpuMatcher, PfacError, PfacTable, emit_records
+from phfpfac_amd.matcher import splitmix64_bytes, tiled_bytes, trace_table_compat
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FP = json.load(open(os.path.join(HERE, "golden", "fingerprints.json")))
+TILE = 16384
+
+
+def gpu_records(table, data, n_owned=None, n_streams=1):
+    with GpuMatcher(0, n_streams) as g:
+        g.load_table(table)
+        return g.scan_bytes(data, n_owned)
+
+
+def oracle_pairs(pattern_file, data, n=None):
+    o = Oracle(pattern_file, 1, 1)          # one automaton; the spec walk needs no PHF
+    pos, ids = o.scan_spec(data, n)
+    o.close()
+    return pos, ids
+
+
+def assert_same(table, rec, pos, ids):
+    assert rec.size == pos.size, f"match count {rec.size} != oracle {pos.size}"
+    np.testing.assert_array_equal(rec["pos"].astype(np.int64), pos)
+    np.testing.assert_array_equal(table.idmap[rec["state"]], ids)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", sorted(FP["cases"]))
+def test_golden_outputs_byte_identical(case, resolve, tmp_path):
+    """GPU_match_result.txt of the whole pipeline == the reference's, for every golden case
+    (the output is independent of stream count and PHF width inside the parity domain)."""
+    c = FP["cases"][case]
+    table = PfacTable.from_file(resolve(c["pattern"]), c["width"])
+    raw = open(resolve(c["input"]), "rb").read()
+    data = raw[:-1]                                           # the reference drops the last byte (main.cc:138)
+    rec = gpu_records(table, data, n_streams=c["streams"])
+    out = tmp_path / "GPU_match_result.txt"
+    nbytes = emit_records(str(out), rec, table.idmap)
+    blob = out.read_bytes()
+    assert rec.size == c["lines"]
+    assert nbytes == len(blob) == c["bytes"]
+    assert hashlib.md5(blob).hexdigest() == c["md5"]
+    if c["verbatim"]:
+        assert blob == open(os.path.join(HERE, "golden", "out", case + ".txt"), "rb").read()
+
+
+def test_gphf_cli_config1(resolve, tmp_path):
+    """The C driver end to end: gphf experimentpattern 2 256 1M -> the BASELINE config-1 golden."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "phfpfac_amd", "bin", "gphf")
+    env = dict(os.environ, PFAC_CHUNK_MB="1")                  # force several pipeline chunks on a 1 MiB input
+    subprocess.check_call([exe, resolve("experimentpattern"), "2", "256", resolve("1M")], cwd=tmp_path, env=env,
+                          stdout=subprocess.DEVNULL)
+    blob = (tmp_path / "GPU_match_result.txt").read_bytes()
+    assert hashlib.md5(blob).hexdigest() == FP["cases"]["exp_x_1M_s1_w256"]["md5"]
+    r = subprocess.run([exe, "a", "b"], cwd=tmp_path, capture_output=True)
+    assert r.returncode != 0 and b"usage:" in r.stderr        # argc check, main.cc:93-96
+
+
+@pytest.mark.parametrize("width", [256, 64, 1024, 4096])
+def test_dictionary_vs_oracle_widths(width, resolve, work_dir):
+    """7 989-word dictionary (tables via L2) on text, every PHF width: records == oracle, in order."""
+    table = PfacTable.from_file(resolve("xaa+xab+xac+xad"), width)
+    data = open(resolve("1M"), "rb").read()[:300000]
+    rec = gpu_records(table, data)
+    pos, ids = oracle_pairs(resolve("xaa+xab+xac+xad"), data)
+    assert_same(table, rec, pos, ids)
+
+
+def test_edge_cases(tmp_path):
+    """Edge cases the reference handles in specific ways."""
+    pat = tmp_path / "p"
+    # prefix chain, single-byte pattern, high bytes, duplicate line (last wins), pattern with \r
+    pat.write_bytes(b"ab\nabcd\nb\nab\n\xff\xfe\nxyz\r\nabcdefghijklmnop\n")
+    table = PfacTable.from_file(str(pat), 256)
+    cases = [
+        b"",                                   # empty input
+        b"b",                                  # one byte
+        b"ab",                                 # match ending exactly at N
+        b"abc",                                # "abcd" would run past N: must not be reported
+        b"xxabcdxx\xff\xfe\xffab",             # several, high bytes
+        b"xyz\r" + b"ab" * 40,
+        (b"abcdefghijklmnop" * 3000)[:TILE * 2 + 5],     # matches straddling tile boundaries
+        b"q" * (TILE - 1) + b"abcd",           # pattern starts in the last byte of a tile
+        b"q" * (TILE - 3) + b"abcdefghijklmnop" + b"q" * 7,
+    ]
+    for data in cases:
+        rec = gpu_records(table, data)
+        pos, ids = oracle_pairs(str(pat), data)
+        assert_same(table, rec, pos, ids)
+    # duplicate rule: "ab" is lines 1 and 4 -> reported as 4 (create_table_reorder.c:366)
+    rec = gpu_records(table, b"ab")
+    assert table.idmap[rec["state"]].tolist() == [4]
+
+
+def test_ragged_sizes_and_alignment(resolve):
+    """Every input length around tile / 16-byte boundaries (the buffer-load tail path)."""
+    table = PfacTable.from_file(resolve("experimentpattern"), 256)
+    base = tiled_bytes(3 * TILE + 64, b"aaaab aa a xaaaaaaa")
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        for n in [1, 2, 15, 16, 17, 1023, 1024, 1025, 4095, 4097, TILE - 1, TILE, TILE + 1, TILE + 15, TILE + 17,
+                  2 * TILE - 1, 2 * TILE, 3 * TILE + 33]:
+            rec = g.scan_bytes(base[:n])
+            pos, ids = oracle_pairs(resolve("experimentpattern"), base[:n])
+            assert_same(table, rec, pos, ids)
+
+
+def test_owned_range_and_shard_invariance(resolve):
+    """Scanning [0,N) in one piece == concatenating K shards that own disjoint ranges and read
+    max_pat_len-1 bytes of halo; shard boundaries land inside matches."""
+    table = PfacTable.from_file(resolve("xaa+xab+xac+xad"), 256)
+    data = np.frombuffer(open(resolve("1M"), "rb").read()[:200003], dtype=np.uint8)
+    N = data.size
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        whole = g.scan_bytes(data)
+        for K in (2, 3, 8):
+            per = -(-N // K)
+            parts = []
+            for k in range(K):
+                lo, hi = k * per, min(N, (k + 1) * per)
+                end = min(N, hi + table.halo)
+                rec = g.scan_bytes(data[lo:end], n_owned=hi - lo).copy()
+                rec["pos"] += np.uint32(lo)
+                parts.append(rec)
+            cat = np.concatenate(parts)
+            np.testing.assert_array_equal(cat["pos"], whole["pos"])
+            np.testing.assert_array_equal(cat["state"], whole["state"])
+
+
+def test_random_patterns_vs_oracle(tmp_path):
+    """Seeded random pattern sets over a small alphabet (dense matches, many >2-deep prefix chains,
+    record-buffer overflow + rescan) and long patterns (halo up to 1022 bytes)."""
+    rng = np.random.default_rng(1234)
+    for trial, (npat, maxlen, alpha) in enumerate([(50, 6, 2), (300, 12, 3), (40, 1023, 2), (2000, 9, 4)]):
+        pats = set()
+        while len(pats) < npat:
+            L = int(rng.integers(1, maxlen + 1))
+            p = bytes(rng.integers(97, 97 + alpha, L, dtype=np.uint8))
+            pats.add(p)
+        pf = tmp_path / f"rp{trial}"
+        pf.write_bytes(b"\n".join(sorted(pats, key=lambda x: rng.random())) + b"\n")
+        table = PfacTable.from_file(str(pf), 256)
+        data = rng.integers(97, 97 + alpha, 70001, dtype=np.uint8)
+        if maxlen > 100:                      # plant a long pattern across a tile boundary
+            longest = max(pats, key=len)
+            data[TILE - 500:TILE - 500 + len(longest)] = np.frombuffer(longest, dtype=np.uint8)
+        rec = gpu_records(table, data)
+        pos, ids = oracle_pairs(str(pf), data)
+        assert_same(table, rec, pos, ids)
+
+
+def test_snort_scale_table_via_l2(resolve):
+    """75 840 patterns / 542 732 states (BASELINE config 5's set): tables far beyond LDS."""
+    table = PfacTable.from_file(resolve("bytefile/1000000byte"), 256)
+    data = open(resolve("bytefile/1000000byte"), "rb").read()[:400000]
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        assert g.info()["variant"] == "tables_via_l2"
+        rec = g.scan_bytes(data)
+    pos, ids = oracle_pairs(resolve("bytefile/1000000byte"), data)
+    assert_same(table, rec, pos, ids)
+
+
+def test_full_size_properties(resolve):
+    """BASELINE config-2 size (1 GiB resident in HBM): properties that need no 1 GiB oracle run.
+    * tiled text: the input has period 402, so matches repeat with the period -> count and checksum
+      follow from one oracle pass over a few periods;
+    * checksum of the whole == sum of checksums of 4 shards with halo (linearity / shard invariance);
+    * records are sorted by position."""
+    import torch
+    para = open(resolve("paragraph402"), "rb").read()
+    N = 1 << 30
+    table = PfacTable.from_file(resolve("experimentpattern"), 256)
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        assert g.info()["variant"] == "tables_in_lds"
+        buf = torch.empty(N + 1024, dtype=torch.uint8, device="cuda:0")
+        g.fill_tiled(buf, N, para)
+        head = buf[:4096].cpu().numpy()
+        np.testing.assert_array_equal(head, tiled_bytes(4096, para))
+        g.reserve(0, 0, N // 8)
+        n = g.scan_resident(N, N, d_input=buf)
+        # oracle on one period-aligned window: per-period match count, with the global end effect
+        reps = 8
+        win = tiled_bytes(402 * reps, para)
+        pos, ids = oracle_pairs(resolve("experimentpattern"), win)
+        inner = (pos >= 402) & (pos < 804)                    # one full period away from both ends
+        per_period = int(inner.sum())
+        full, tail = divmod(N, 402)
+        assert tail >= 3                                      # no match of the last full period is cut by N
+        # matches in the last partial period: oracle over the true tail bytes
+        last = tiled_bytes(tail, para, phase=0)
+        lpos, _ = oracle_pairs(resolve("experimentpattern"), last)
+        assert n == per_period * full + lpos.size
+        total_sum = g.checksum(n)
+        # sortedness of a large prefix and of the tail, checked on the host
+        rec_head = g.records_to_host(min(n, 1 << 20))
+        assert (np.diff(rec_head["pos"].astype(np.int64)) >= 0).all()
+        # linearity: 4 shards with halo, each into its own record region
+        K, per = 4, N // 4
+        s = 0
+        cnt = 0
+        for k in range(K):
+            lo, hi = k * per, (k + 1) * per
+            end = min(N, hi + table.halo)
+            nk = g.scan_resident(hi - lo, end - lo, d_input=int(buf.data_ptr()) + lo)
+            s = (s + g.checksum(nk, base=lo)) % (1 << 64)
+            cnt += nk
+        assert cnt == n and s == total_sum
+        # and the checksum formula itself agrees with the oracle on a small prefix
+        m = 1 << 20
+        nm = g.scan_resident(m, m, d_input=buf)
+        opos, oids = oracle_pairs(resolve("experimentpattern"), tiled_bytes(m, para))
+        assert nm == opos.size and g.checksum(nm) == match_checksum(opos, oids)
+
+
+def test_random_fill_matches_cpu_twin_and_oracle(resolve):
+    import torch
+    n = 1 << 22
+    table = PfacTable.from_file(resolve("bytefile/10000byte"), 256)
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+        g.fill_random(buf, n, 0x5048465046414331)
+        host = buf.cpu().numpy()
+        np.testing.assert_array_equal(host, splitmix64_bytes(n, 0x5048465046414331))
+        g.reserve(0, 0, 1 << 16)
+        cnt = g.scan_resident(n, n, d_input=buf)
+        rec = g.records_to_host(cnt)
+    pos, ids = oracle_pairs(resolve("bytefile/10000byte"), host)
+    assert_same(table, rec, pos, ids)
+
+
+def test_compat_seam_dense_layout(resolve):
+    """pfac_trace_table_compat fills the reference's dense input_size x max_pat_len array
+    (master_kernel.cu:104-115,236) from tables in the reference's own r/HT/val form."""
+    o = Oracle(resolve("xaa"), 1, 1)
+    o.ffdm(1024, exact=True)                                  # the reference's exact FFDM layout
+    L = o.L
+    st = o.stats()
+    trie = o.trie()
+    nf = st["final"]
+    table = PfacTable.from_reference_arrays(
+        trie[nf + 1], np.ctypeslib.as_array(L.orc_phf_r(o.m, 0), (st["r_size"],)),
+        np.ctypeslib.as_array(L.orc_phf_HT(o.m, 0), (st["ht_size"],)),
+        np.ctypeslib.as_array(L.orc_phf_val(o.m, 0), (st["ht_size"],)), o.idmap(), 1024, st["state_num"], nf,
+        st["ht_size"], L.orc_max_len(o.m))
+    data = np.frombuffer(open(resolve("1M"), "rb").read()[:50000], dtype=np.uint8)
+    dense = trace_table_compat(data, table, 0)
+    pos, ids = o.scan_spec(data)
+    exp = np.full_like(dense, 0xFFFFFFFF)
+    inv = {int(v): k for k, v in enumerate(o.idmap())}
+    fill = {}
+    for p, i in zip(pos.tolist(), ids.tolist()):
+        j = fill.get(p, 0)
+        exp[p, j] = inv[i]
+        fill[p] = j + 1
+    np.testing.assert_array_equal(dense, exp)
+    o.close()
+
+
+def test_errors_are_loud(resolve):
+    with GpuMatcher(0, 1) as g:
+        with pytest.raises(PfacError):
+            g.scan_async(16)                                   # scan before a table upload
+    with pytest.raises(PfacError):
+        GpuMatcher(99, 1)                                      # no such device
