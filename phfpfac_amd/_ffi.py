@@ -116,6 +116,14 @@ def hip_lib() -> C.CDLL:
         if not os.path.exists(path):
             raise OSError(f"{path} is missing: the HIP extension was not built and there is no CPU fallback "
                           f"(run __graft_entry__.build() or `make -C phfpfac_amd/csrc`)")
+        # One HIP runtime per process: libpfac_hip.so needs libamdhip64.so.7 by soname, and PyTorch
+        # bundles its own copy.  If ours pulled in /opt/rocm's first, torch.cuda would later find a
+        # second, conflicting HSA runtime ("No HIP GPUs are available").  Importing torch first makes
+        # the loader bind this library to the copy torch already mapped.  (The C CLI links /opt/rocm.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         vp, u64, i = C.c_void_p, C.c_uint64, C.c_int
         L.pfac_device_count.argtypes = [C.POINTER(i)]

@@ -76,8 +76,11 @@ class Oracle:
 
     def _arrays(self, o):
         cnt = self.L.orc_matches_count(o)
-        pos = np.ctypeslib.as_array(self.L.orc_matches_pos(o), (max(cnt, 1),))[:cnt].copy()
-        ids = np.ctypeslib.as_array(self.L.orc_matches_id(o), (max(cnt, 1),))[:cnt].copy()
+        if cnt == 0:
+            self.L.orc_matches_free(o)
+            return np.empty(0, dtype=np.int64), np.empty(0, dtype=np.int32)
+        pos = np.ctypeslib.as_array(self.L.orc_matches_pos(o), (cnt,)).copy()
+        ids = np.ctypeslib.as_array(self.L.orc_matches_id(o), (cnt,)).copy()
         self.L.orc_matches_free(o)
         return pos, ids
 

@@ -105,7 +105,7 @@ def test_edge_cases(tmp_path):
         assert_same(table, rec, pos, ids)
     # duplicate rule: "ab" is lines 1 and 4 -> reported as 4 (create_table_reorder.c:366)
     rec = gpu_records(table, b"ab")
-    assert table.idmap[rec["state"]].tolist() == [4]
+    assert [(int(p), int(i)) for p, i in zip(rec["pos"], table.idmap[rec["state"]])] == [(0, 4), (1, 3)]
 
 
 def test_ragged_sizes_and_alignment(resolve):
