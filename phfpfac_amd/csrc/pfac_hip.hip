@@ -44,24 +44,29 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// geometry
+// geometry.  The unit of work is a WAVE TILE: 4 KiB of input owned by one wavefront.
 constexpr int WAVE = 64;
-constexpr int BLOCK = 256;
-constexpr int NW = BLOCK / WAVE;
-constexpr int SUB = WAVE * 16;             // bytes one wave covers with one 16-B-per-lane load
-constexpr int SUBS = 4;                    // such loads per wave per tile
-constexpr int WCHUNK = SUB * SUBS;         // 4 KiB per wave
-constexpr int TILE = NW * WCHUNK;          // 16 KiB per workgroup iteration
+constexpr int SUB = WAVE * 16;             // bytes one wave covers with one 16-B-per-lane load (1 KiB)
+constexpr int SUBS = 4;                    // such sub-tiles per wave tile
+constexpr int WTILE = SUB * SUBS;          // 4096: tile-local positions fit 12 bits
 constexpr int HALO_MAX = 1024;             // >= max_pat_len - 1 (patterns are < 1024 bytes), multiple of 16
+constexpr int QCAP = SUB + WAVE;           // survivor FIFO: < 64 carried over + up to 1024 appended
+#ifndef PFAC_CAPW
+#define PFAC_CAPW 384
+#endif
+constexpr int CAPW = PFAC_CAPW;            // records staged in LDS per tile per buffer (more -> synchronous re-walk)
+constexpr int PACK_STATE_BITS = 20;        // staged record = pos:12 | state:20 (larger automata re-walk)
+constexpr int MAX_WAVES_PER_BLOCK = 16;     // 15 compute waves + the coordinator
+constexpr int LDS_TOTAL = 160 * 1024;
+constexpr int LDS_TABLE_MAX = 40 * 1024;   // PHF tables up to this size are staged in LDS (variant 0)
 
-constexpr int OFF_TILE = 0;
-constexpr int OFF_QUEUE = OFF_TILE + TILE + HALO_MAX + 16;
-constexpr int OFF_S0 = OFF_QUEUE + NW * SUB * 2;
-constexpr int OFF_FLAG = OFF_S0 + 256 * 4;
-constexpr int OFF_MISC = OFF_FLAG + 256;
-constexpr int OFF_TAB = OFF_MISC + 64;
-constexpr int LDS_BASE_BYTES = OFF_TAB;
-constexpr int LDS_TABLE_MAX = 40 * 1024;   // tables up to this size are staged in LDS (variant 0)
+// shared (per workgroup) LDS: root row, 8 pre-shifted root-flag tables, then the PHF tables (variant 0)
+constexpr int SH_HDR = 0;                  // round rings (H_* below)
+constexpr int SH_S0 = SH_HDR + 1024;
+constexpr int SH_FTAB = SH_S0 + 256 * 4;
+constexpr int SH_TAB = SH_FTAB + 8 * 256;
+// per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
+constexpr int PW_FIXED = WTILE + QCAP * 2 + 2 * CAPW * 4;
 
 constexpr unsigned long long ST_AGG = 1ull << 62;
 constexpr unsigned long long ST_INCL = 2ull << 62;
@@ -79,7 +84,10 @@ struct ScanArgs {
     const int *r;
     const int2 *T;
     int r_words, t_entries;
-    int ht_size, wbit, num_final, halo;
+    int ht_size, wbit, num_final, halo;   // halo: bytes readable past a tile, multiple of 16
+    int shared_bytes, pw_bytes;           // LDS carve: shared region, then one region per wave
+    unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
+    unsigned stage_cap;                   // CAPW, or 0 when final states do not fit the packed staging word
     unsigned n_tiles;
     unsigned *ctl;                 // [0] ticket, [1] error flags, [2..3] total matches (u64)
     unsigned long long *status;    // one look-back word per tile
@@ -87,12 +95,17 @@ struct ScanArgs {
 
 // ---------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
-__device__ __forceinline__ unsigned wave_incl_scan(unsigned x, int lane) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        unsigned t = __shfl_up(x, d, WAVE);
-        if (lane >= d) x += t;
-    }
+
+// Inclusive prefix sum over the 64 lanes with DPP (no LDS round trips): Hillis-Steele inside each
+// row of 16 lanes (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows
+// 2 and 3.  Lanes without a source keep `old` = 0 (bound_ctrl off), i.e. add the identity.
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
     return x;
 }
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x) {
@@ -110,6 +123,44 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Workgroup organisation.  A workgroup = NC compute waves + 1 coordinator wave, and proceeds in
+// ROUNDS: in round r compute wave c scans tile  batch(r) * NC + c.  Batches are handed out in order by
+// one global atomic per round (a ticket per 4 KiB tile would hit the ~88 M atomics/s an address
+// sustains on MI355X and cap the scan at 0.36 TB/s), taken two rounds ahead by the coordinator.
+// The coordinator also sums the round's per-wave match counts, publishes the batch aggregate and
+// runs the decoupled look-back over BATCHES (a few hundred are in flight chip-wide, so the window is
+// short), while the compute waves are already scanning the next round; they pick the batch's
+// record base up from LDS when they emit, one round later.  No workgroup barrier in the loop.
+// Whoever holds batch G knows every batch < G is held by a running workgroup -- all the look-back
+// needs; nothing depends on dispatch order, residency or placement.
+//
+// LDS header (unsigned words), rings of 8 rounds indexed by r & 7:
+constexpr int RING = 8;
+constexpr int H_BATCH = 0;                 // batch id of round r
+constexpr int H_EPOCH = 8;                 // == r + 1 once H_BATCH (and a zeroed H_ARRIVED) are valid
+constexpr int H_ARRIVED = 16;              // compute waves that have posted their count
+constexpr int H_READY = 24;                // == r + 1 once H_GBASE is valid
+constexpr int H_GBASE = 32;                // 2 words per round: records before the batch
+constexpr int H_CNT = 48;                  // 16 words per round: match count of each compute wave
+constexpr int H_WORDS = H_CNT + RING * 16;
+
+__device__ __forceinline__ unsigned lds_load(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(unsigned *p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Spin (bounded) until *p == want.  Wave-uniform: every lane reads the same word.
+__device__ __forceinline__ bool lds_wait_eq(const unsigned *p, unsigned want, unsigned *err, unsigned code) {
+    unsigned spins = 0;
+    while (lds_load(p) != want) {
+        if (++spins >= SPIN_MAX) { atomicOr(err, code); return false; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // decoupled look-back over per-tile match counts.  Each status word is ONE
 // naturally aligned 8-byte granule {flag:2, value:62} moved only by relaxed
@@ -122,16 +173,19 @@ __device__ __forceinline__ void st_store(unsigned long long *p, unsigned long lo
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by wave 0 only, all 64 lanes.  Returns the number of matches in all
-// tiles before `tile` (wave-uniform).  Every spin is bounded: on timeout the
-// error word is set and the kernel still terminates.
+// A tile first publishes its own count (aggregate); tile 0's count is already its inclusive prefix.
+__device__ __forceinline__ void publish_aggregate(unsigned long long *status, unsigned tile, unsigned long long tot, int lane) {
+    if (lane == 0) st_store(&status[tile], (tile == 0 ? ST_INCL : ST_AGG) | tot);
+}
+
+// All 64 lanes of one wave.  Returns the number of matches in all tiles before `tile`
+// (wave-uniform) and publishes the tile's inclusive prefix.  Every spin is bounded: on timeout
+// the error word is set and the kernel still terminates.  Tickets are handed out in order and a
+// wave publishes its aggregate without waiting for anything, so every predecessor polled here
+// belongs to a wave that is running or done.
 __device__ unsigned long long lookback(unsigned long long *status, unsigned tile, unsigned long long tot, int lane,
                                        unsigned *err) {
-    if (tile == 0) {
-        if (lane == 0) st_store(&status[0], ST_INCL | tot);
-        return 0;
-    }
-    if (lane == 0) st_store(&status[tile], ST_AGG | tot);
+    if (tile == 0) return 0;
     unsigned long long excl = 0;
     long long idx = (long long)tile - 1 - lane;       // lane L inspects predecessor tile-1-L
     bool failed = false;
@@ -170,11 +224,18 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
 // ---------------------------------------------------------------------------
 // One step of the perfect-hash lookup (master_kernel.cu:52-63): returns the
 // next state or -1.  HT/val are interleaved as int2 {owner row, next state}.
+// W8: PHF width 256 (the benchmark width) -> row == state, col == byte.
+template <bool W8>
 __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, int ch, int wbit, int ht_size) {
-    const int key = (state << 8) | ch;
-    const int row = key >> wbit;
-    const int col = key & ((1 << wbit) - 1);
-    const int idx = R[row] + col;
+    int row, idx;
+    if (W8) {
+        row = state;
+        idx = R[state] + ch;
+    } else {
+        const int key = (state << 8) | ch;
+        row = key >> wbit;
+        idx = R[row] + (key & ((1 << wbit) - 1));
+    }
     if ((unsigned)idx >= (unsigned)ht_size) return -1;
     const int2 e = T[idx];
     return e.x == row ? e.y : -1;
@@ -182,6 +243,7 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 
 // Walk from tile-local position `pos`; counts final states reached, keeps the
 // first two in m0/m1.  lim = first tile-local byte that may not be read.
+template <bool W8>
 __device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s0, const int *R, const int2 *T,
                                          unsigned pos, unsigned lim, int wbit, int ht_size, int num_final,
                                          unsigned &m0, unsigned &m1) {
@@ -195,197 +257,337 @@ __device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s
             n++;
         }
         if (p >= lim) break;
-        s = phf_step(R, T, s, tile[p], wbit, ht_size);
+        s = phf_step<W8>(R, T, s, tile[p], wbit, ht_size);
         p++;
     }
     return n;
 }
 
-// Same walk, storing every final state from the `skip`-th on (rare path: more
-// than two patterns start at one offset).
+// Same walk for the rare offsets where more than two patterns start: every final state from the
+// third on goes to the LDS staging buffer (packed) or straight to global memory.
+template <bool W8, bool DIRECT>
 __device__ __forceinline__ void walk_store(const unsigned char *tile, const int *s0, const int *R, const int2 *T,
                                            unsigned pos, unsigned lim, int wbit, int ht_size, int num_final,
-                                           unsigned skip, pfac_record *out, unsigned long long ri,
-                                           unsigned long long cap, unsigned gpos) {
+                                           unsigned *stage, unsigned stage_cap, pfac_record *out,
+                                           unsigned long long out_cap, unsigned long long ri, unsigned gpos) {
     unsigned n = 0;
     int s = s0[tile[pos]];
     unsigned p = pos + 1;
     while (s >= 0) {
         if (s < num_final) {
-            if (n >= skip && ri + n < cap) {
-                pfac_record rec;
-                rec.pos = gpos;
-                rec.state = (unsigned)s;
-                out[ri + n] = rec;
+            if (n >= 2) {
+                if (DIRECT) {
+                    if (ri + n < out_cap) {
+                        pfac_record rec;
+                        rec.pos = gpos;
+                        rec.state = (unsigned)s;
+                        out[ri + n] = rec;
+                    }
+                } else if (ri + n < stage_cap) {
+                    stage[ri + n] = pos | ((unsigned)s << 12);
+                }
             }
             n++;
         }
         if (p >= lim) break;
-        s = phf_step(R, T, s, tile[p], wbit, ht_size);
+        s = phf_step<W8>(R, T, s, tile[p], wbit, ht_size);
         p++;
     }
 }
 
-// One pass of one wave over its 4 KiB chunk.  WRITE == false: returns the
-// wave's match count.  WRITE == true: emits records starting at index wrun.
-template <bool WRITE>
-__device__ __forceinline__ unsigned long long wave_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
+// One round: up to 64 survivors (one per lane, in position order) are walked; their records are
+// appended at index `wrun` of the staging buffer (DIRECT == false) or of the global record array.
+template <bool W8, bool DIRECT>
+__device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned char *tile, const int *s0, const int *R,
+                                            const int2 *T, const unsigned short *q, unsigned qi, bool active,
+                                            unsigned *stage, unsigned lim, unsigned long long tile_base,
+                                            unsigned long long wrun) {
+    unsigned n = 0, m0 = 0, m1 = 0, pos = 0;
+    if (active) {
+        pos = q[qi];
+        n = walk<W8>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
+    }
+    const unsigned inc = wave_incl_scan(n);
+    const unsigned long long ri = wrun + (inc - n);
+    if (DIRECT) {
+        pfac_record rec;
+        rec.pos = (unsigned)(tile_base + pos);
+        if (n > 0 && ri < a.out_cap) { rec.state = m0; a.out[ri] = rec; }
+        if (n > 1 && ri + 1 < a.out_cap) { rec.state = m1; a.out[ri + 1] = rec; }
+        if (n > 2)
+            walk_store<W8, true>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, nullptr, 0, a.out, a.out_cap, ri, rec.pos);
+    } else {
+        if (n > 0 && ri < a.stage_cap) stage[ri] = pos | (m0 << 12);
+        if (n > 1 && ri + 1 < a.stage_cap) stage[ri + 1] = pos | (m1 << 12);
+        if (n > 2)
+            walk_store<W8, false>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, stage, a.stage_cap, nullptr, 0, ri, 0);
+    }
+    return bcast_last(inc);
+}
+
+// Compaction + walk over one wave tile.  Survivors (set bits of the per-lane masks) are appended,
+// in position order, to a FIFO in LDS; whenever 64 are pending a full round runs, so lanes stay
+// busy even when only one offset in thirteen survives the root test.  Returns the tile's match
+// count; with DIRECT the records are written at global index wrun onwards.
+template <bool W8, bool DIRECT>
+__device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
                                                         const int *R, const int2 *T, unsigned short *q,
-                                                        const unsigned (&masks)[SUBS], int wave, int lane,
+                                                        unsigned *stage, const unsigned (&masks)[SUBS], int lane,
                                                         unsigned lim, unsigned long long tile_base,
                                                         unsigned long long wrun) {
-    unsigned lane_total = 0;
+    unsigned tail = 0;                         // pending survivors, always < 64 between sub-tiles
 #pragma unroll
     for (int j = 0; j < SUBS; j++) {
         const unsigned mask = masks[j];
         const unsigned cnt = __popc(mask);
-        const unsigned incl = wave_incl_scan(cnt, lane);
+        const unsigned incl = wave_incl_scan(cnt);
         const unsigned S = bcast_last(incl);
         if (S == 0) continue;
-        const unsigned lpos = wave * WCHUNK + j * SUB + lane * 16;
-        unsigned o = incl - cnt;
+        const unsigned lpos = j * SUB + lane * 16;
+        unsigned o = tail + incl - cnt;
         for (unsigned m = mask; m; m &= m - 1) q[o++] = (unsigned short)(lpos + (__ffs(m) - 1));
+        tail += S;
         wave_lds_sync();
-        for (unsigned base = 0; base < S; base += WAVE) {
-            const unsigned qi = base + lane;
-            unsigned n = 0, m0 = 0, m1 = 0, pos = 0;
-            if (qi < S) {
-                pos = q[qi];
-                n = walk(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
-            }
-            if (!WRITE) {
-                lane_total += n;
-            } else {
-                const unsigned inc = wave_incl_scan(n, lane);
-                const unsigned long long ri = wrun + (inc - n);
-                const unsigned gpos = (unsigned)(tile_base + pos);
-                if (n > 0 && ri < a.out_cap) {
-                    pfac_record rec;
-                    rec.pos = gpos;
-                    rec.state = m0;
-                    a.out[ri] = rec;
-                }
-                if (n > 1 && ri + 1 < a.out_cap) {
-                    pfac_record rec;
-                    rec.pos = gpos;
-                    rec.state = m1;
-                    a.out[ri + 1] = rec;
-                }
-                if (n > 2)
-                    walk_store(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, 2, a.out, ri, a.out_cap, gpos);
-                wrun += bcast_last(inc);
-            }
+        unsigned h = 0;
+        for (; h + WAVE <= tail; h += WAVE)
+            wrun += round64<W8, DIRECT>(a, tile, s0, R, T, q, h + lane, true, stage, lim, tile_base, wrun);
+        if (h) {                               // move the < 64 left-overs to the front
+            const unsigned rem = tail - h;
+            unsigned short v = 0;
+            if ((unsigned)lane < rem) v = q[h + lane];
+            wave_lds_sync();
+            if ((unsigned)lane < rem) q[lane] = v;
+            wave_lds_sync();
+            tail = rem;
         }
-        wave_lds_sync();   // queue is reused by the next sub-tile
     }
-    if (!WRITE) return wave_sum64(lane_total);
+    if (tail) wrun += round64<W8, DIRECT>(a, tile, s0, R, T, q, lane, (unsigned)lane < tail, stage, lim, tile_base, wrun);
     return wrun;
 }
 
-template <bool TLDS>
-__global__ __launch_bounds__(BLOCK) void pfac_scan_kernel(ScanArgs a) {
+// Staged records of one tile -> global memory, in order.
+__device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base,
+                                         unsigned long long tile_base, int lane) {
+    for (unsigned i = lane; i < cnt; i += WAVE) {
+        const unsigned v = stage[i];
+        pfac_record rec;
+        rec.pos = (unsigned)tile_base | (v & 0xFFFu);      // tile_base is a multiple of 4096
+        rec.state = v >> 12;
+        if (base + i < a.out_cap) a.out[base + i] = rec;
+    }
+}
+
+// Root test: 16-bit mask of the lane's 16 bytes that have an edge out of the root.
+//   ROOT == 1: exactly one such byte value -> exact SWAR compare, flags gathered with v_dot4
+//   ROOT == 0: one LDS lookup per byte in pre-shifted flag tables (table k holds flag << k)
+template <int ROOT>
+__device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned char *ftab, unsigned root_x4) {
+    if (ROOT == 1) {
+        unsigned nm[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned x = w[i] ^ root_x4;                            // zero byte <=> match
+            nm[i] = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;  // 0x80 where the byte is NOT a match
+        }
+        unsigned lo = __builtin_amdgcn_udot4(nm[0], 0x08040201u, 0u, false);
+        lo = __builtin_amdgcn_udot4(nm[1], 0x80402010u, lo, false);       // = 128 * (not-match bits 0..7)
+        unsigned hi = __builtin_amdgcn_udot4(nm[2], 0x08040201u, 0u, false);
+        hi = __builtin_amdgcn_udot4(nm[3], 0x80402010u, hi, false);
+        return ~((lo >> 7) | (hi << 1)) & 0xFFFFu;
+    } else {
+        unsigned fa = 0, fb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned ba = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            const unsigned bb = (w[2 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
+            fa |= ftab[k * 256 + ba];
+            fb |= ftab[k * 256 + bb];
+        }
+        return fa | (fb << 8);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The scan kernel.  Workgroups share the read-only tables staged in LDS once; after that there is
+// no workgroup barrier: compute waves pipeline  [loads of round r+1 in flight | scan round r |
+// emit round r-1]  and meet the coordinator only through the LDS rings above.
+template <bool TLDS, bool W8, int ROOT>
+__global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *tile = smem + OFF_TILE;
-    unsigned short *queue = reinterpret_cast<unsigned short *>(smem + OFF_QUEUE);
-    int *s0 = reinterpret_cast<int *>(smem + OFF_S0);
-    unsigned char *flag = smem + OFF_FLAG;
-    unsigned *misc = reinterpret_cast<unsigned *>(smem + OFF_MISC);   // [0..3] wave totals, [4] tile, [6..7] base
+    unsigned *hdr = reinterpret_cast<unsigned *>(smem + SH_HDR);
+    int *s0 = reinterpret_cast<int *>(smem + SH_S0);
+    unsigned char *ftab = smem + SH_FTAB;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = tid >> 6;
+    const int nc = (int)(blockDim.x >> 6) - 1;             // compute waves; wave nc coordinates
+    unsigned *err = &a.ctl[1];
 
-    // ---- once per workgroup: root row, root flags, (small) PHF tables -> LDS
-    {
-        const int v = a.s0[tid];
-        s0[tid] = v;
-        flag[tid] = v >= 0 ? 1 : 0;
+    // ---- once per workgroup: rings cleared, root row, root flag tables, (small) PHF tables -> LDS
+    for (int i = tid; i < H_WORDS; i += blockDim.x) hdr[i] = 0;
+    for (int i = tid; i < 256; i += blockDim.x) {
+        const int v = a.s0[i];
+        s0[i] = v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ftab[k * 256 + i] = v >= 0 ? (unsigned char)(1u << k) : (unsigned char)0;
     }
     const int *R = a.r;
     const int2 *T = a.T;
     if (TLDS) {
-        int *lr = reinterpret_cast<int *>(smem + OFF_TAB);
-        int2 *lt = reinterpret_cast<int2 *>(smem + OFF_TAB + ((a.r_words * 4 + 15) & ~15));
-        for (int i = tid; i < a.r_words; i += BLOCK) lr[i] = a.r[i];
-        for (int i = tid; i < a.t_entries; i += BLOCK) lt[i] = a.T[i];
+        int *lr = reinterpret_cast<int *>(smem + SH_TAB);
+        int2 *lt = reinterpret_cast<int2 *>(smem + SH_TAB + ((a.r_words * 4 + 15) & ~15));
+        for (int i = tid; i < a.r_words; i += blockDim.x) lr[i] = a.r[i];
+        for (int i = tid; i < a.t_entries; i += blockDim.x) lt[i] = a.T[i];
         R = lr;
         T = lt;
     }
-    unsigned short *q = queue + wave * SUB;
+    __syncthreads();                           // the only workgroup barrier
 
-    for (;;) {
-        __syncthreads();                       // previous tile fully consumed (LDS + misc)
-        if (tid == 0) misc[4] = atomicAdd(&a.ctl[0], 1u);
-        __syncthreads();
-        const unsigned t = misc[4];
-        if (t >= a.n_tiles) break;
-        const unsigned long long tile_base = (unsigned long long)t * TILE;
-        const unsigned long long remain = a.n_avail - tile_base;           // > 0
-        const unsigned lim = remain < (unsigned long long)(TILE + a.halo) ? (unsigned)remain : (unsigned)(TILE + a.halo);
-
-        // ---- stage: own 4 KiB per wave (+ halo by wave 0) -> LDS.  The buffer descriptor covers
-        // whole 16-B units only, so every dword of a load is either fully inside or reads as 0.
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned char *>(a.in + tile_base), 0, (int)(lim & ~15u), 0x00020000);
-        {
-            u32x4 w[SUBS];
-#pragma unroll
-            for (int j = 0; j < SUBS; j++)
-                w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wave * WCHUNK + j * SUB + lane * 16, 0, 0);
-            u32x4 hw = {0u, 0u, 0u, 0u};
-            const bool has_halo = wave == 0 && lane * 16 < a.halo;
-            if (has_halo) hw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, TILE + lane * 16, 0, 0);
-#pragma unroll
-            for (int j = 0; j < SUBS; j++)
-                *reinterpret_cast<u32x4 *>(tile + wave * WCHUNK + j * SUB + lane * 16) = w[j];
-            if (has_halo) *reinterpret_cast<u32x4 *>(tile + TILE + lane * 16) = hw;
-        }
-        __syncthreads();                       // tile + halo visible to every wave
-        if (lim & 15u) {                       // ragged end of the input (last tile only): patch the tail bytes
-            if (tid < (int)(lim & 15u)) tile[(lim & ~15u) + tid] = a.in[tile_base + (lim & ~15u) + tid];
-            __syncthreads();
-        }
-
-        // ---- root test: one flag lookup per byte -> 16-bit survivor mask per lane per sub-tile
-        unsigned masks[SUBS];
-#pragma unroll
-        for (int j = 0; j < SUBS; j++) {
-            const unsigned off = wave * WCHUNK + j * SUB + lane * 16;
-            const u32x4 w = *reinterpret_cast<const u32x4 *>(tile + off);
-            unsigned m = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const unsigned b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                m |= (unsigned)flag[b] << k;
-            }
-            // only offsets below n_owned start a walk
-            const unsigned long long g = tile_base + off;
-            if (g + 16 > a.n_owned) m = g >= a.n_owned ? 0u : (m & ((1u << (unsigned)(a.n_owned - g)) - 1u));
-            masks[j] = m;
-        }
-
-        // ---- pass 1: count
-        const unsigned long long wtot = wave_pass<false>(a, tile, s0, R, T, q, masks, wave, lane, lim, tile_base, 0);
-        if (lane == 0) misc[wave] = (unsigned)wtot;
-        __syncthreads();
-        if (wave == 0) {
-            const unsigned long long tot = (unsigned long long)misc[0] + misc[1] + misc[2] + misc[3];
-            const unsigned long long excl = lookback(a.status, t, tot, lane, &a.ctl[1]);
+    if (wave == nc) {
+        // ================= coordinator =================
+        auto take_batch = [&](unsigned r) -> unsigned {     // ticket for round r -> ring, returns batch id
+            unsigned g = 0;
             if (lane == 0) {
-                misc[6] = (unsigned)excl;
-                misc[7] = (unsigned)(excl >> 32);
-                if (t == a.n_tiles - 1) {
+                g = atomicAdd(&a.ctl[0], 1u);
+                lds_store(&hdr[H_ARRIVED + (r & 7)], 0u);
+                lds_store(&hdr[H_BATCH + (r & 7)], g);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_store(&hdr[H_EPOCH + (r & 7)], r + 1);
+            }
+            return __builtin_amdgcn_readfirstlane(g);
+        };
+        unsigned g_cur = take_batch(0);
+        unsigned g_nxt = take_batch(1);
+        for (unsigned r = 0;; r++) {
+            const unsigned long long first = (unsigned long long)g_cur * (unsigned)nc;
+            if (first >= a.n_tiles) break;     // batches are handed out in order: nothing left for this workgroup
+            const unsigned g_nxt2 = take_batch(r + 2);      // two rounds ahead of the compute waves
+            const unsigned long long left = a.n_tiles - first;
+            const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
+            if (!lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
+            const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
+            const unsigned long long tot = wave_sum64(c);
+            publish_aggregate(a.status, g_cur, tot, lane);
+            const unsigned long long excl = lookback(a.status, g_cur, tot, lane, err);
+            if (lane == 0) {
+                hdr[H_GBASE + (r & 7) * 2] = (unsigned)excl;
+                hdr[H_GBASE + (r & 7) * 2 + 1] = (unsigned)(excl >> 32);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_store(&hdr[H_READY + (r & 7)], r + 1);
+                if (first + n_valid >= a.n_tiles) {         // this batch holds the last tile: grand total
                     a.ctl[2] = (unsigned)(excl + tot);
                     a.ctl[3] = (unsigned)((excl + tot) >> 32);
                 }
             }
+            g_cur = g_nxt;
+            g_nxt = g_nxt2;
         }
-        __syncthreads();
-        // ---- pass 2: emit (skipped by waves without matches)
-        if (misc[wave] != 0) {
-            unsigned long long wrun = ((unsigned long long)misc[7] << 32) | misc[6];
-            for (int k = 0; k < wave; k++) wrun += misc[k];
-            wave_pass<true>(a, tile, s0, R, T, q, masks, wave, lane, lim, tile_base, wrun);
+        return;
+    }
+
+    // ================= compute waves =================
+    unsigned char *tile = smem + a.shared_bytes + wave * a.pw_bytes;
+    unsigned short *q = reinterpret_cast<unsigned short *>(tile + WTILE + a.halo);
+    unsigned *stage0 = reinterpret_cast<unsigned *>(tile + WTILE + a.halo + QCAP * 2);
+
+    // prefetch registers: the wave's 4 KiB + halo
+    u32x4 w[SUBS];
+    u32x4 hw = {0u, 0u, 0u, 0u};
+    auto issue_loads = [&](unsigned long long tt) {
+        const unsigned long long tb = tt * WTILE;
+        const unsigned long long remain = a.n_avail - tb;
+        const unsigned lm = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
+        // the descriptor covers whole 16-B units only: every dword of a load is fully inside or reads as 0
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char *>(a.in + tb), 0, (int)(lm & ~15u), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < SUBS; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, j * SUB + lane * 16, 0, 0);
+        if (lane * 16 < a.halo) hw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, WTILE + lane * 16, 0, 0);
+    };
+    // record base of this wave's tile of round rr: batch base + counts of the waves before it
+    auto record_base = [&](unsigned rr, unsigned long long &base) -> bool {
+        if (!lds_wait_eq(&hdr[H_READY + (rr & 7)], rr + 1, err, 8u)) return false;
+        const unsigned long long g = ((unsigned long long)hdr[H_GBASE + (rr & 7) * 2 + 1] << 32) | hdr[H_GBASE + (rr & 7) * 2];
+        const unsigned c = lane < wave ? hdr[H_CNT + (rr & 7) * 16 + lane] : 0u;
+        base = g + wave_sum64(c);
+        return true;
+    };
+
+    unsigned r = 0;
+    if (!lds_wait_eq(&hdr[H_EPOCH], 1u, err, 16u)) return;
+    unsigned long long t = (unsigned long long)hdr[H_BATCH] * (unsigned)nc + (unsigned)wave;
+    if (t >= a.n_tiles) return;
+    issue_loads(t);
+
+    bool have_prev = false;
+    unsigned prev_cnt = 0, buf = 0;
+    unsigned long long prev_t = 0;
+
+    for (;;) {
+        const unsigned long long tile_base = t * WTILE;
+        const unsigned long long remain = a.n_avail - tile_base;           // > 0
+        const unsigned lim = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
+
+        // ---- registers -> LDS (tile + halo), then start the next round's loads right away
+#pragma unroll
+        for (int j = 0; j < SUBS; j++) *reinterpret_cast<u32x4 *>(tile + j * SUB + lane * 16) = w[j];
+        if (lane * 16 < a.halo) *reinterpret_cast<u32x4 *>(tile + WTILE + lane * 16) = hw;
+        if (lim & 15u) {                       // ragged end of the input (last tile only): patch the tail bytes
+            wave_lds_sync();
+            if (lane < (int)(lim & 15u)) tile[(lim & ~15u) + lane] = a.in[tile_base + (lim & ~15u) + lane];
         }
+        wave_lds_sync();
+        bool more = lds_wait_eq(&hdr[H_EPOCH + ((r + 1) & 7)], r + 2, err, 16u);
+        unsigned long long t_next = 0;
+        if (more) {
+            t_next = (unsigned long long)hdr[H_BATCH + ((r + 1) & 7)] * (unsigned)nc + (unsigned)wave;
+            more = t_next < a.n_tiles;
+        }
+        if (more) issue_loads(t_next);
+
+        // ---- root test -> 16-bit survivor mask per lane per sub-tile
+        unsigned masks[SUBS];
+#pragma unroll
+        for (int j = 0; j < SUBS; j++) {
+            const unsigned off = j * SUB + lane * 16;
+            const u32x4 ww = *reinterpret_cast<const u32x4 *>(tile + off);
+            unsigned m = root_mask<ROOT>(ww, ftab, a.root_byte);
+            const unsigned long long g = tile_base + off;                  // only offsets below n_owned start a walk
+            if (g + 16 > a.n_owned) m = g >= a.n_owned ? 0u : (m & ((1u << (unsigned)(a.n_owned - g)) - 1u));
+            masks[j] = m;
+        }
+
+        // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
+        unsigned *stage = stage0 + buf * CAPW;
+        const unsigned long long cnt = tile_pass<W8, false>(a, tile, s0, R, T, q, stage, masks, lane, lim, tile_base, 0);
+        if (lane == 0) {
+            hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            atomicAdd(&hdr[H_ARRIVED + (r & 7)], 1u);
+        }
+
+        if (cnt > a.stage_cap) {
+            // staging overflowed (or the automaton is too large for packed staging): emit this tile
+            // now, while its bytes are still in LDS -- wait for the batch base, walk again to global
+            unsigned long long base = 0;
+            if (record_base(r, base)) tile_pass<W8, true>(a, tile, s0, R, T, q, stage, masks, lane, lim, tile_base, base);
+        }
+        // ---- emit the PREVIOUS round's tile: the coordinator has had a whole round for its look-back
+        if (have_prev) {
+            unsigned long long base = 0;
+            if (record_base(r - 1, base)) copy_out(a, stage0 + (buf ^ 1) * CAPW, prev_cnt, base, prev_t * WTILE, lane);
+        }
+        have_prev = cnt <= a.stage_cap;
+        prev_t = t;
+        prev_cnt = (unsigned)cnt;
+        buf ^= 1;
+        if (!more) break;
+        t = t_next;
+        r++;
+    }
+    if (have_prev) {
+        unsigned long long base = 0;
+        if (record_base(r, base)) copy_out(a, stage0 + (buf ^ 1) * CAPW, prev_cnt, base, prev_t * WTILE, lane);
     }
 }
 
@@ -492,7 +694,9 @@ struct pfac_ctx {
     int width_bit = 0, num_final = 0, max_pat_len = 0, max_row = 0, ht_size = 0, state_num = 0;
     bool have_table = false;
     int variant = 1;
-    int lds_bytes = 0;
+    const void *kernel = nullptr;
+    int lds_bytes = 0, shared_bytes = 0, pw_bytes = 0, halo = 0, waves_per_block = 0, root_mode = 0;
+    unsigned root_byte = 0, stage_cap = 0;
     int grid_blocks = 0;
     std::string err;
     std::mutex mu;
@@ -531,22 +735,38 @@ int ensure_status(pfac_ctx *ctx, Slot &s, uint64_t n_tiles) {
     return PFAC_OK;
 }
 
-int configure_kernel(pfac_ctx *ctx) {
+int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     // table bytes if staged in LDS: r (16-B rounded) + T
     const size_t tbytes = align_up((size_t)ctx->max_row * 4, 16) + (size_t)ctx->ht_size * 8;
     ctx->variant = tbytes <= (size_t)LDS_TABLE_MAX ? 0 : 1;
-    ctx->lds_bytes = LDS_BASE_BYTES + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : 0);
-    int per_cu = 0;
-    if (ctx->variant == 0) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)pfac_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_bytes));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfac_scan_kernel<true>, BLOCK, ctx->lds_bytes));
-    } else {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)pfac_scan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_bytes));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfac_scan_kernel<false>, BLOCK, ctx->lds_bytes));
-    }
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    ctx->grid_blocks = ctx->n_cu * per_cu;
+    if (getenv("PFAC_FORCE_L2")) ctx->variant = 1;             // tuning knob: tables via L2 even if they fit LDS
+    int halo = ctx->max_pat_len > 1 ? ctx->max_pat_len - 1 : 0;
+    ctx->halo = (halo + 15) & ~15;
+    ctx->shared_bytes = SH_TAB + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : 0);
+    ctx->pw_bytes = (int)align_up((size_t)PW_FIXED + ctx->halo, 16);
+    int nwb = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes + 1;     // compute waves + the coordinator (no LDS region)
+    if (nwb > MAX_WAVES_PER_BLOCK) nwb = MAX_WAVES_PER_BLOCK;
+    if (getenv("PFAC_NWB") && atoi(getenv("PFAC_NWB")) > 0 && atoi(getenv("PFAC_NWB")) < nwb) nwb = atoi(getenv("PFAC_NWB"));
+    if (nwb < 2) return fail(ctx, PFAC_E_INTERNAL, "LDS budget cannot hold one compute wave");
+    ctx->waves_per_block = nwb;
+    ctx->lds_bytes = ctx->shared_bytes + (nwb - 1) * ctx->pw_bytes;
+    // one workgroup per CU: ask for more than half of the LDS so two never share a CU while another idles
+    if (ctx->lds_bytes < LDS_TOTAL / 2 + 256) ctx->lds_bytes = LDS_TOTAL / 2 + 256;
+    ctx->grid_blocks = ctx->n_cu;
+    // root fan-out 1 -> exact SWAR root test (ROOT = 1), else LDS flag tables (ROOT = 0)
+    int fan = 0, rb = 0;
+    for (int i = 0; i < 256; i++) if (s0_host[i] >= 0) { fan++; rb = i; }
+    ctx->root_mode = fan == 1 ? 1 : 0;
+    ctx->root_byte = (unsigned)rb * 0x01010101u;
+    ctx->stage_cap = ctx->num_final <= (1 << PACK_STATE_BITS) ? (unsigned)CAPW : 0u;
+    const bool w8 = ctx->width_bit == 8;
+    const void *k[2][2][2] = {
+        {{(const void *)pfac_scan_kernel<false, false, 0>, (const void *)pfac_scan_kernel<false, false, 1>},
+         {(const void *)pfac_scan_kernel<false, true, 0>, (const void *)pfac_scan_kernel<false, true, 1>}},
+        {{(const void *)pfac_scan_kernel<true, false, 0>, (const void *)pfac_scan_kernel<true, false, 1>},
+         {(const void *)pfac_scan_kernel<true, true, 0>, (const void *)pfac_scan_kernel<true, true, 1>}}};
+    ctx->kernel = k[ctx->variant == 0 ? 1 : 0][w8 ? 1 : 0][ctx->root_mode];
+    HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_bytes));
     return PFAC_OK;
 }
 
@@ -580,7 +800,9 @@ int install_table(pfac_ctx *ctx, const int *d_blob, const int32_t *hdr, size_t n
     ctx->width_bit = wbit; ctx->num_final = num_final; ctx->max_pat_len = max_pat_len;
     ctx->max_row = max_row; ctx->ht_size = ht_size; ctx->state_num = state_num;
     ctx->have_table = true;
-    return configure_kernel(ctx);
+    int32_t s0_host[256];
+    HIP_TRY(ctx, hipMemcpy(s0_host, ctx->d_s0, sizeof s0_host, hipMemcpyDeviceToHost));
+    return configure_kernel(ctx, s0_host);
 }
 
 }  // namespace
@@ -681,7 +903,7 @@ int pfac_slot_reserve(pfac_ctx *ctx, int slot, uint64_t input_bytes, uint64_t re
     Slot &s = ctx->slots[slot];
     if (input_bytes > s.input_cap) {
         if (s.d_input) { HIP_TRY(ctx, hipFree(s.d_input)); s.d_input = nullptr; s.input_cap = 0; }
-        const uint64_t cap = align_up(input_bytes, TILE) + HALO_MAX + 256;
+        const uint64_t cap = align_up(input_bytes, WTILE) + HALO_MAX + 256;
         HIP_TRY(ctx, hipMalloc((void **)&s.d_input, cap));
         s.input_cap = cap;
     }
@@ -729,7 +951,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     if (!d_input && n_avail > s.input_cap) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: n_avail exceeds the reserved input buffer");
     if (!d_records && capacity) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: no record buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint64_t n_tiles = (n_owned + TILE - 1) / TILE;
+    const uint64_t n_tiles = (n_owned + WTILE - 1) / WTILE;
     s.last_cap = capacity;
     s.scanned = true;
     rc = ensure_status(ctx, s, n_tiles);
@@ -744,17 +966,16 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T;
         a.r_words = ctx->max_row; a.t_entries = ctx->ht_size;
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
-        int halo = ctx->max_pat_len > 1 ? ctx->max_pat_len - 1 : 0;
-        a.halo = (halo + 15) & ~15;
+        a.halo = ctx->halo;
+        a.shared_bytes = ctx->shared_bytes; a.pw_bytes = ctx->pw_bytes;
+        a.root_byte = ctx->root_byte; a.stage_cap = ctx->stage_cap;
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = s.d_ctl;
         a.status = reinterpret_cast<unsigned long long *>(s.d_ctl + 16);
-        uint64_t grid = (uint64_t)ctx->grid_blocks < n_tiles ? (uint64_t)ctx->grid_blocks : n_tiles;
-        if (ctx->variant == 0)
-            hipLaunchKernelGGL(pfac_scan_kernel<true>, dim3((unsigned)grid), dim3(BLOCK), ctx->lds_bytes, s.stream, a);
-        else
-            hipLaunchKernelGGL(pfac_scan_kernel<false>, dim3((unsigned)grid), dim3(BLOCK), ctx->lds_bytes, s.stream, a);
-        HIP_TRY(ctx, hipGetLastError());
+        const uint64_t want = (n_tiles + ctx->waves_per_block - 2) / (ctx->waves_per_block - 1);   // batches
+        uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
+        void *kargs[] = {&a};
+        HIP_TRY(ctx, hipLaunchKernel(ctx->kernel, dim3((unsigned)grid), dim3(WAVE * ctx->waves_per_block), kargs, (size_t)ctx->lds_bytes, s.stream));
     }
     HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
     HIP_TRY(ctx, hipMemcpyAsync(s.h_ctl, s.d_ctl, 16, hipMemcpyDeviceToHost, s.stream));
@@ -866,7 +1087,7 @@ int pfac_scan_info(pfac_ctx *ctx, int *variant, int *tile_bytes, int *grid_block
     if (!ctx) return fail(nullptr, PFAC_E_ARG, "null context");
     if (!ctx->have_table) return fail(ctx, PFAC_E_STATE, "no table uploaded");
     if (variant) *variant = ctx->variant;
-    if (tile_bytes) *tile_bytes = TILE;
+    if (tile_bytes) *tile_bytes = WTILE;
     if (grid_blocks) *grid_blocks = ctx->grid_blocks;
     if (lds_bytes) *lds_bytes = ctx->lds_bytes;
     return PFAC_OK;
