@@ -66,7 +66,8 @@ constexpr int SH_S0 = SH_HDR + 1024;
 constexpr int SH_FTAB = SH_S0 + 256 * 4;
 constexpr int SH_TAB = SH_FTAB + 8 * 256;
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
-constexpr int PW_FIXED = WTILE + QCAP * 2 + 2 * CAPW * 4;
+constexpr int NBUF = 3;                    // staging buffers: a tile's records are emitted two rounds later
+constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
 
 constexpr unsigned long long ST_AGG = 1ull << 62;
 constexpr unsigned long long ST_INCL = 2ull << 62;
@@ -90,7 +91,8 @@ struct ScanArgs {
     unsigned stage_cap;                   // CAPW, or 0 when final states do not fit the packed staging word
     unsigned n_tiles;
     unsigned *ctl;                 // [0] ticket, [1] error flags, [2..3] total matches (u64)
-    unsigned long long *status;    // one look-back word per tile
+    unsigned long long *status;    // one look-back word per batch
+    unsigned long long *dbg;       // PFAC_TRACE only: per-round timestamps (10 ns units), else null
 };
 
 // ---------------------------------------------------------------------------
@@ -142,7 +144,8 @@ constexpr int H_ARRIVED = 16;              // compute waves that have posted the
 constexpr int H_READY = 24;                // == r + 1 once H_GBASE is valid
 constexpr int H_GBASE = 32;                // 2 words per round: records before the batch
 constexpr int H_CNT = 48;                  // 16 words per round: match count of each compute wave
-constexpr int H_WORDS = H_CNT + RING * 16;
+constexpr int H_URGENT = H_CNT + RING * 16; // != 0: a wave of round r needs the batch base right away (staging overflow)
+constexpr int H_WORDS = H_URGENT + RING;
 
 __device__ __forceinline__ unsigned lds_load(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -178,40 +181,52 @@ __device__ __forceinline__ void publish_aggregate(unsigned long long *status, un
     if (lane == 0) st_store(&status[tile], (tile == 0 ? ST_INCL : ST_AGG) | tot);
 }
 
-// All 64 lanes of one wave.  Returns the number of matches in all tiles before `tile`
-// (wave-uniform) and publishes the tile's inclusive prefix.  Every spin is bounded: on timeout
-// the error word is set and the kernel still terminates.  Tickets are handed out in order and a
-// wave publishes its aggregate without waiting for anything, so every predecessor polled here
-// belongs to a wave that is running or done.
+// All 64 lanes of one wave.  Returns the number of matches in all batches before `tile`
+// (wave-uniform) and publishes the batch's inclusive prefix.  A few hundred batches are in flight
+// chip-wide (one per workgroup), most of them of the same "generation", so the window is WIDE:
+// 4 x 64 predecessors are fetched at once (one memory round trip), and the scan stops at the nearest
+// predecessor that already knows its inclusive prefix -- only predecessors nearer than that one have
+// to be published before this batch can finish.  Every spin is bounded: on timeout the error word is
+// set and the kernel still terminates.  Batches are handed out in order and an aggregate is
+// published without waiting for anything, so every predecessor polled here belongs to a workgroup
+// that is running or done.
+constexpr int LB_WIN = 4;
 __device__ unsigned long long lookback(unsigned long long *status, unsigned tile, unsigned long long tot, int lane,
                                        unsigned *err) {
     if (tile == 0) return 0;
     unsigned long long excl = 0;
-    long long idx = (long long)tile - 1 - lane;       // lane L inspects predecessor tile-1-L
+    long long top = (long long)tile - 1;              // nearest predecessor not yet accounted for
+    unsigned spins = 0;
     bool failed = false;
-    for (;;) {
-        unsigned long long st = ST_INCL;              // tiles before 0: inclusive prefix 0
-        bool bad = false;
-        if (idx >= 0) {
-            unsigned spins = 0;
-            for (;;) {
-                st = st_load(&status[idx]);
-                if (st >> 62) break;
-                if (++spins >= SPIN_MAX) { bad = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
+    while (top >= 0) {
+        unsigned long long st[LB_WIN];
+#pragma unroll
+        for (int k = 0; k < LB_WIN; k++) {
+            const long long idx = top - lane - WAVE * k;   // position WAVE*k + lane behind `top`
+            st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
         }
-        if (__any(bad)) { failed = true; break; }
-        unsigned long long incl_mask = __ballot((st >> 62) == 2);
-        unsigned long long v = st & ST_VAL;
-        if (incl_mask) {
-            int first = __ffsll((long long)incl_mask) - 1;   // nearest predecessor that knows its prefix
-            if (lane > first) v = 0;
-            excl += wave_sum64(v);
-            break;
+        // first unpublished and first inclusive position in the window (wave-uniform)
+        int pz = LB_WIN * WAVE, pi = LB_WIN * WAVE;
+#pragma unroll
+        for (int k = LB_WIN - 1; k >= 0; k--) {
+            const unsigned long long z = __ballot((st[k] >> 62) == 0);
+            const unsigned long long in = __ballot((st[k] >> 62) == 2);
+            if (z) pz = WAVE * k + __ffsll((long long)z) - 1;
+            if (in) pi = WAVE * k + __ffsll((long long)in) - 1;
         }
+        const int upto = pi < pz ? pi : pz - 1;       // positions 0..upto are usable now (all published)
+        if (pi >= pz && pz == 0) {                    // the nearest one is not published yet: poll again
+            if (++spins >= SPIN_MAX) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        unsigned long long v = 0;
+#pragma unroll
+        for (int k = 0; k < LB_WIN; k++)
+            if (WAVE * k + lane <= upto) v += st[k] & ST_VAL;
         excl += wave_sum64(v);
-        idx -= WAVE;
+        if (pi < pz) break;                           // reached a predecessor with an inclusive prefix
+        top -= upto + 1;                              // consumed the published aggregates; continue behind them
     }
     if (failed) {
         if (lane == 0) atomicOr(err, 1u);
@@ -450,6 +465,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             if (lane == 0) {
                 g = atomicAdd(&a.ctl[0], 1u);
                 lds_store(&hdr[H_ARRIVED + (r & 7)], 0u);
+                lds_store(&hdr[H_URGENT + (r & 7)], 0u);
                 lds_store(&hdr[H_BATCH + (r & 7)], g);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 lds_store(&hdr[H_EPOCH + (r & 7)], r + 1);
@@ -458,30 +474,51 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         };
         unsigned g_cur = take_batch(0);
         unsigned g_nxt = take_batch(1);
-        for (unsigned r = 0;; r++) {
-            const unsigned long long first = (unsigned long long)g_cur * (unsigned)nc;
-            if (first >= a.n_tiles) break;     // batches are handed out in order: nothing left for this workgroup
-            const unsigned g_nxt2 = take_batch(r + 2);      // two rounds ahead of the compute waves
-            const unsigned long long left = a.n_tiles - first;
-            const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
-            if (!lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
-            const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
-            const unsigned long long tot = wave_sum64(c);
-            publish_aggregate(a.status, g_cur, tot, lane);
-            const unsigned long long excl = lookback(a.status, g_cur, tot, lane, err);
+        // The look-back of round r normally runs one round LATE (after round r+1's aggregate went out):
+        // by then every batch of the same generation has published its aggregate, so it costs one
+        // memory round trip instead of a wait for the slowest workgroup; the compute waves emit two
+        // rounds late and never notice.
+        bool pend = false;                     // round r-1 still needs its look-back
+        unsigned pend_r = 0, pend_g = 0;
+        unsigned long long pend_tot = 0, pend_end = 0;
+        auto resolve = [&](unsigned rr, unsigned g, unsigned long long tot, unsigned long long end_tile) {
+            const unsigned long long excl = lookback(a.status, g, tot, lane, err);
             if (lane == 0) {
-                hdr[H_GBASE + (r & 7) * 2] = (unsigned)excl;
-                hdr[H_GBASE + (r & 7) * 2 + 1] = (unsigned)(excl >> 32);
+                hdr[H_GBASE + (rr & 7) * 2] = (unsigned)excl;
+                hdr[H_GBASE + (rr & 7) * 2 + 1] = (unsigned)(excl >> 32);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                lds_store(&hdr[H_READY + (r & 7)], r + 1);
-                if (first + n_valid >= a.n_tiles) {         // this batch holds the last tile: grand total
+                lds_store(&hdr[H_READY + (rr & 7)], rr + 1);
+                if (end_tile >= a.n_tiles) {                // this batch holds the last tile: grand total
                     a.ctl[2] = (unsigned)(excl + tot);
                     a.ctl[3] = (unsigned)((excl + tot) >> 32);
                 }
             }
+        };
+        for (unsigned r = 0;; r++) {
+            const unsigned long long first = (unsigned long long)g_cur * (unsigned)nc;
+            if (first >= a.n_tiles) break;     // batches are handed out in order: nothing left for this workgroup
+            const unsigned g_nxt2 = take_batch(r + 2);      // two rounds ahead of the compute waves
+            const bool trace = a.dbg && blockIdx.x < 8 && r < 64 && lane == 0;
+            unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + r) * 32;
+            if (trace) tr[0] = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long left = a.n_tiles - first;
+            const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
+            if (!lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
+            if (trace) tr[1] = __builtin_amdgcn_s_memrealtime();
+            const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
+            const unsigned long long tot = wave_sum64(c);
+            publish_aggregate(a.status, g_cur, tot, lane);
+            if (pend) resolve(pend_r, pend_g, pend_tot, pend_end);
+            pend = true; pend_r = r; pend_g = g_cur; pend_tot = tot; pend_end = first + n_valid;
+            if (lds_load(&hdr[H_URGENT + (r & 7)]) != 0) {  // a wave overflowed its staging: it is waiting for this base
+                resolve(pend_r, pend_g, pend_tot, pend_end);
+                pend = false;
+            }
+            if (trace) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = g_cur; }
             g_cur = g_nxt;
             g_nxt = g_nxt2;
         }
+        if (pend) resolve(pend_r, pend_g, pend_tot, pend_end);
         return;
     }
 
@@ -519,15 +556,19 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
     if (t >= a.n_tiles) return;
     issue_loads(t);
 
-    bool have_prev = false;
-    unsigned prev_cnt = 0, buf = 0;
-    unsigned long long prev_t = 0;
+    // pending[k]: the tile scanned k+1 rounds ago still sits in its staging buffer
+    bool have1 = false, have2 = false;
+    unsigned cnt1 = 0, cnt2 = 0, buf = 0;      // buf: staging buffer of the current round, (r % NBUF)
+    unsigned long long t1 = 0, t2 = 0;
 
     for (;;) {
         const unsigned long long tile_base = t * WTILE;
         const unsigned long long remain = a.n_avail - tile_base;           // > 0
         const unsigned lim = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
 
+        const bool trace = a.dbg && blockIdx.x < 8 && r < 64 && lane == 0 && wave == 0;
+        unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + r) * 32;
+        if (trace) tr[4] = __builtin_amdgcn_s_memrealtime();
         // ---- registers -> LDS (tile + halo), then start the next round's loads right away
 #pragma unroll
         for (int j = 0; j < SUBS; j++) *reinterpret_cast<u32x4 *>(tile + j * SUB + lane * 16) = w[j];
@@ -537,6 +578,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             if (lane < (int)(lim & 15u)) tile[(lim & ~15u) + lane] = a.in[tile_base + (lim & ~15u) + lane];
         }
         wave_lds_sync();
+        if (trace) tr[5] = __builtin_amdgcn_s_memrealtime();
         bool more = lds_wait_eq(&hdr[H_EPOCH + ((r + 1) & 7)], r + 2, err, 16u);
         unsigned long long t_next = 0;
         if (more) {
@@ -557,37 +599,49 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             masks[j] = m;
         }
 
+        if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * CAPW;
         const unsigned long long cnt = tile_pass<W8, false>(a, tile, s0, R, T, q, stage, masks, lane, lim, tile_base, 0);
+        if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
+        if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
+        const bool overflow = cnt > a.stage_cap;
         if (lane == 0) {
             hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
+            if (overflow) lds_store(&hdr[H_URGENT + (r & 7)], 1u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             atomicAdd(&hdr[H_ARRIVED + (r & 7)], 1u);
         }
 
-        if (cnt > a.stage_cap) {
+        if (overflow) {
             // staging overflowed (or the automaton is too large for packed staging): emit this tile
             // now, while its bytes are still in LDS -- wait for the batch base, walk again to global
             unsigned long long base = 0;
             if (record_base(r, base)) tile_pass<W8, true>(a, tile, s0, R, T, q, stage, masks, lane, lim, tile_base, base);
         }
-        // ---- emit the PREVIOUS round's tile: the coordinator has had a whole round for its look-back
-        if (have_prev) {
+        // ---- emit the tile of TWO rounds ago: its batch base has long been resolved
+        if (have2) {
             unsigned long long base = 0;
-            if (record_base(r - 1, base)) copy_out(a, stage0 + (buf ^ 1) * CAPW, prev_cnt, base, prev_t * WTILE, lane);
+            const bool okb = record_base(r - 2, base);
+            if (trace) tr[9] = __builtin_amdgcn_s_memrealtime();
+            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
         }
-        have_prev = cnt <= a.stage_cap;
-        prev_t = t;
-        prev_cnt = (unsigned)cnt;
-        buf ^= 1;
+        if (trace) tr[8] = __builtin_amdgcn_s_memrealtime();
+        have2 = have1; cnt2 = cnt1; t2 = t1;
+        have1 = !overflow; cnt1 = (unsigned)cnt; t1 = t;
+        buf = (buf + 1) % NBUF;
         if (!more) break;
         t = t_next;
         r++;
     }
-    if (have_prev) {
+    // drain: the last two rounds' tiles (staged in buffers buf+1 [two rounds ago] and buf+2 [last round])
+    if (have2) {
         unsigned long long base = 0;
-        if (record_base(r, base)) copy_out(a, stage0 + (buf ^ 1) * CAPW, prev_cnt, base, prev_t * WTILE, lane);
+        if (record_base(r - 1, base)) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
+    }
+    if (have1) {
+        unsigned long long base = 0;
+        if (record_base(r, base)) copy_out(a, stage0 + ((buf + 2) % NBUF) * CAPW, cnt1, base, t1 * WTILE, lane);
     }
 }
 
@@ -678,6 +732,7 @@ struct Slot {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t last_cap = 0;
     bool scanned = false;
+    unsigned long long *d_dbg = nullptr;  // PFAC_TRACE
 };
 
 }  // namespace
@@ -972,6 +1027,12 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = s.d_ctl;
         a.status = reinterpret_cast<unsigned long long *>(s.d_ctl + 16);
+        a.dbg = nullptr;
+        if (getenv("PFAC_TRACE")) {
+            if (!s.d_dbg) HIP_TRY(ctx, hipMalloc((void **)&s.d_dbg, 8 * 64 * 32 * 8));
+            HIP_TRY(ctx, hipMemsetAsync(s.d_dbg, 0, 8 * 64 * 32 * 8, s.stream));
+            a.dbg = s.d_dbg;
+        }
         const uint64_t want = (n_tiles + ctx->waves_per_block - 2) / (ctx->waves_per_block - 1);   // batches
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
         void *kargs[] = {&a};
@@ -991,6 +1052,12 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
     const uint64_t total = ((uint64_t)s.h_ctl[3] << 32) | s.h_ctl[2];
     if (n_matches) *n_matches = total;
+    if (s.d_dbg && getenv("PFAC_TRACE")) {
+        std::vector<unsigned long long> h(8 * 64 * 32);
+        if (hipMemcpy(h.data(), s.d_dbg, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(getenv("PFAC_TRACE"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+    }
     if (s.h_ctl[1] != 0) return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a look-back timeout");
     if (total > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "more matches than record capacity");
     return PFAC_OK;
