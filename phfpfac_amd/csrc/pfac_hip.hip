@@ -256,26 +256,68 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
     return e.x == row ? e.y : -1;
 }
 
-// Walk from tile-local position `pos`; counts final states reached, keeps the
-// first two in m0/m1.  lim = first tile-local byte that may not be read.
+// Walk from tile-local position `pos`; counts final states reached, keeps the first two in m0/m1.
+// lim = first tile-local byte that may not be read.  All 64 lanes step together (the trip count is
+// the deepest walk in the wave) and dead lanes are predicated with selects instead of nested
+// divergent branches -- far fewer exec-mask / scalar instructions per step.  Input bytes come four
+// at a time from one aligned 8-byte LDS read, so a step's only dependent LDS accesses are R and T.
 template <bool W8>
 __device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s0, const int *R, const int2 *T,
-                                         unsigned pos, unsigned lim, int wbit, int ht_size, int num_final,
-                                         unsigned &m0, unsigned &m1) {
-    unsigned n = 0;
-    int s = s0[tile[pos]];
-    unsigned p = pos + 1;
-    while (s >= 0) {
-        if (s < num_final) {
-            m0 = n == 0 ? (unsigned)s : m0;     // selects, not an indexed pair (that would go to scratch)
-            m1 = n == 1 ? (unsigned)s : m1;
-            n++;
+                                         unsigned pos, bool active, unsigned lim, int wbit, int ht_size,
+                                         int num_final, unsigned &m0, unsigned &m1) {
+    const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
+    unsigned lo = t32[pos >> 2], hi = t32[(pos >> 2) + 1];     // may run a few bytes past lim: never used
+    unsigned win = __builtin_amdgcn_alignbyte(hi, lo, pos & 3u);   // bytes pos .. pos+3
+    int s = s0[win & 0xFFu];
+    s = active ? s : -1;
+    unsigned n = 0, p = pos + 1;
+    bool go = false;
+    // account for the state just reached; false when no lane of the wave can go on
+    auto reached = [&]() -> bool {
+        const bool alive = s >= 0;
+        const bool fin = alive && s < num_final;
+        m0 = (fin && n == 0) ? (unsigned)s : m0;               // selects, not an indexed pair (that would go to scratch)
+        m1 = (fin && n == 1) ? (unsigned)s : m1;
+        n += fin ? 1u : 0u;
+        go = alive && p < lim;
+        return __any(go);
+    };
+    // one transition on input byte ch (straight-line: dead lanes look up a harmless, valid slot)
+    auto step = [&](unsigned ch) {
+        const int sg = go ? s : 0;
+        int row, idx;
+        if (W8) {
+            row = sg;
+            idx = R[sg] + (int)ch;
+        } else {
+            const int key = (sg << 8) | (int)ch;
+            row = key >> wbit;
+            idx = R[row] + (key & ((1 << wbit) - 1));
         }
-        if (p >= lim) break;
-        s = phf_step<W8>(R, T, s, tile[p], wbit, ht_size);
+        const unsigned ic = min((unsigned)idx, (unsigned)ht_size - 1u);
+        const int2 e = T[ic];
+        s = (go && ic == (unsigned)idx && e.x == row) ? e.y : -1;
         p++;
+    };
+    if (!reached()) return n;
+    step((win >> 8) & 0xFFu);
+    if (!reached()) return n;
+    step((win >> 16) & 0xFFu);
+    if (!reached()) return n;
+    step(win >> 24);
+    for (;;) {                                                 // deeper than 4 bytes: next aligned window
+        if (!reached()) return n;
+        lo = t32[p >> 2];
+        hi = t32[(p >> 2) + 1];
+        win = __builtin_amdgcn_alignbyte(hi, lo, p & 3u);
+        step(win & 0xFFu);
+        if (!reached()) return n;
+        step((win >> 8) & 0xFFu);
+        if (!reached()) return n;
+        step((win >> 16) & 0xFFu);
+        if (!reached()) return n;
+        step(win >> 24);
     }
-    return n;
 }
 
 // Same walk for the rare offsets where more than two patterns start: every final state from the
@@ -317,11 +359,9 @@ __device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned ch
                                             const int2 *T, const unsigned short *q, unsigned qi, bool active,
                                             unsigned *stage, unsigned lim, unsigned long long tile_base,
                                             unsigned long long wrun) {
-    unsigned n = 0, m0 = 0, m1 = 0, pos = 0;
-    if (active) {
-        pos = q[qi];
-        n = walk<W8>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
-    }
+    unsigned m0 = 0, m1 = 0;
+    const unsigned pos = active ? q[qi] : 0u;
+    const unsigned n = walk<W8>(tile, s0, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
     const unsigned inc = wave_incl_scan(n);
     const unsigned long long ri = wrun + (inc - n);
     if (DIRECT) {
@@ -593,10 +633,14 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         for (int j = 0; j < SUBS; j++) {
             const unsigned off = j * SUB + lane * 16;
             const u32x4 ww = *reinterpret_cast<const u32x4 *>(tile + off);
-            unsigned m = root_mask<ROOT>(ww, ftab, a.root_byte);
-            const unsigned long long g = tile_base + off;                  // only offsets below n_owned start a walk
-            if (g + 16 > a.n_owned) m = g >= a.n_owned ? 0u : (m & ((1u << (unsigned)(a.n_owned - g)) - 1u));
-            masks[j] = m;
+            masks[j] = root_mask<ROOT>(ww, ftab, a.root_byte);
+        }
+        if (tile_base + WTILE > a.n_owned) {   // last tile only: offsets at or past n_owned start no walk
+#pragma unroll
+            for (int j = 0; j < SUBS; j++) {
+                const unsigned long long g = tile_base + j * SUB + lane * 16;
+                if (g + 16 > a.n_owned) masks[j] = g >= a.n_owned ? 0u : (masks[j] & ((1u << (unsigned)(a.n_owned - g)) - 1u));
+            }
         }
 
         if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
