@@ -315,6 +315,7 @@ int orc_ffdm(orc_model *m, int width, int exact) {
 }
 
 int orc_phf_stat(const orc_model *m, int c, int what) {
+    if (!m->NumKeys) return -1;   /* orc_ffdm not run */
     switch (what) {
         case 0: return m->NumKeys[c];
         case 1: return m->MaxKey[c];

@@ -1,0 +1,103 @@
+"""The N>1 path on CPU: world_size-2 `gloo` processes exercise the sharding plan, the table broadcast and the
+ordered record gather of phfpfac_amd/dist.py.  There is no GPU here and the product has no CPU scan, so each
+rank's shard records are produced by the CHECKER (the oracle's spec walk over that shard's owned range + halo);
+what is under test is that sharding + broadcast + gather reassemble exactly the unsharded result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+DATA = os.path.join(HERE, "golden", "data")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, pat_path, n_total, out_dir):
+    sys.path.insert(0, REPO); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from orc import Oracle
+    from phfpfac_amd import PfacTable, RECORD_DTYPE
+    from phfpfac_amd import dist as pdist
+    from phfpfac_amd.matcher import tiled_bytes
+    dev = torch.device("cpu")
+    # rank 0 builds the table on the host and broadcasts the image
+    table = PfacTable.from_file(pat_path, 256) if rank == 0 else None
+    blob, table = pdist.broadcast_table(table, dev, 0)
+    ref = PfacTable.from_file(pat_path, 256)
+    assert np.array_equal(blob.numpy(), ref.blob())
+    assert table.state_num == ref.state_num and table.max_pat_len == ref.max_pat_len
+    # this rank's shard of the global stream (generated locally, as bench.py does on the GPU)
+    para = open(os.path.join(DATA, "paragraph402"), "rb").read()
+    lo, hi, end = pdist.shard_read_range(n_total, rank, world, table.halo)
+    assert lo % 16 == 0 and (hi % 16 == 0 or hi == n_total)
+    shard = tiled_bytes(end - lo, para, phase=lo % len(para))
+    o = Oracle(pat_path, 1, 1)
+    pos, ids = o.scan_spec(shard)                 # walks may use the halo ...
+    keep = pos < (hi - lo)                        # ... but only owned offsets report
+    inv = {int(v): k for k, v in enumerate(o.idmap())}
+    rec = np.empty(int(keep.sum()), dtype=RECORD_DTYPE)
+    rec["pos"] = pos[keep]
+    rec["state"] = [inv[int(i)] for i in ids[keep]]
+    o.close()
+    counts = pdist.gather_counts(rec.size, dev)
+    assert counts[rank] == rec.size
+    t = torch.from_numpy(rec.view(np.int64).copy()) if rec.size else torch.empty(0, dtype=torch.int64)
+    gathered = pdist.gather_records(t, rec.size, counts, dst=0)
+    if rank == 0:
+        allrec = pdist.split_gathered(gathered, counts, n_total, world)
+        np.save(os.path.join(out_dir, "gathered.npy"), allrec)
+        np.save(os.path.join(out_dir, "counts.npy"), np.array(counts))
+    else:
+        assert gathered is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pattern,n_total", [("xaa", 100003), ("experimentpattern", 65536 + 402)])
+def test_two_rank_sharded_scan_reassembles(pattern, n_total, tmp_path):
+    from orc import Oracle
+    from phfpfac_amd import PfacTable
+    from phfpfac_amd.matcher import tiled_bytes
+    pat_path = os.path.join(DATA, pattern)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, pat_path, n_total, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    para = open(os.path.join(DATA, "paragraph402"), "rb").read()
+    whole = tiled_bytes(n_total, para)
+    o = Oracle(pat_path, 1, 1)
+    pos, ids = o.scan_spec(whole)
+    table = PfacTable.from_file(pat_path, 256)
+    assert got.size == pos.size
+    np.testing.assert_array_equal(got["pos"].astype(np.int64), pos)
+    np.testing.assert_array_equal(table.idmap[got["state"]], ids)
+    assert (np.diff(got["pos"].astype(np.int64)) >= 0).all()
+    o.close()
+
+
+def test_shard_plan_properties():
+    from phfpfac_amd.dist import shard_range, shard_read_range
+    for n in (0, 1, 15, 16, 17, 1000, 1 << 20, (1 << 35) + 5):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                assert lo == prev and lo <= hi <= n and (lo % 16 == 0 or lo == n)
+                prev = hi
+                lo2, hi2, end = shard_read_range(n, r, world, 227)
+                assert (lo2, hi2) == (lo, hi) and hi <= end <= min(n, hi + 227)
+            assert prev == n

@@ -1,0 +1,129 @@
+"""Host-side C table builder (phfpfac_amd/csrc/pfac_table.c through the C-ABI): lookup(state, byte) must equal
+the oracle's dense trie in EVERY cell, for every PHF width; plus the reader's error behaviour and the blob image."""
+import numpy as np
+import pytest
+
+from orc import Oracle
+from phfpfac_amd import PfacError, PfacTable
+
+
+def lookup_all(t):
+    S, w, wb = t.state_num, t.width, t.width_bit
+    key = (np.arange(S, dtype=np.int64)[:, None] << 8) + np.arange(256)[None, :]
+    row, col = key >> wb, key & (w - 1)
+    idx = t.r[row] + col
+    ok = (idx >= 0) & (idx < t.ht_size)
+    idc = np.clip(idx, 0, t.ht_size - 1)
+    ok &= t.HT[idc] == row
+    return np.where(ok, t.val[idc], -1)
+
+
+@pytest.mark.parametrize("name", ["experimentpattern", "xaa", "xaa+xab+xac+xad", "bytefile/10000byte", "bytefile/100000byte"])
+@pytest.mark.parametrize("width", [256, 1024, 4096, 64, 1])
+def test_lookup_equals_dense_trie(name, width, resolve):
+    t = PfacTable.from_file(resolve(name), width)
+    o = Oracle(resolve(name), 1, 1)
+    dense = o.trie()
+    assert t.state_num == dense.shape[0] and t.num_final == o.stats()["final"]
+    assert t.max_pat_len == o.L.orc_max_len(o.m)
+    assert (lookup_all(t) == dense).all()
+    assert (t.idmap == o.idmap()).all()
+    assert (t.s0 == dense[t.num_final + 1]).all()
+    assert t.max_row == t.state_num * 256 // width + 1
+    # the C lookup helper agrees on a sample
+    rng = np.random.default_rng(0)
+    for s, c in zip(rng.integers(0, t.state_num, 200), rng.integers(0, 256, 200)):
+        assert t.lookup(int(s), int(c)) == dense[s, c]
+    o.close()
+
+
+def test_snort_scale_set_builds_fast_and_correct(resolve):
+    """75 840 patterns / 542 732 states (the reference preallocates 4 GiB per chunk and sorts rows in O(R^2))."""
+    import time
+    t0 = time.time()
+    t = PfacTable.from_file(resolve("bytefile/1000000byte"), 256)
+    assert time.time() - t0 < 20
+    assert (t.n_patterns, t.state_num, t.max_pat_len) == (75840, 542732, 228)
+    o = Oracle(resolve("bytefile/1000000byte"), 1, 1)
+    dense = o.trie()
+    rng = np.random.default_rng(1)
+    S = rng.integers(0, t.state_num, 20000)
+    got = lookup_all_rows(t, S)
+    assert (got == dense[S]).all()
+    o.close()
+
+
+def lookup_all_rows(t, states):
+    key = (states.astype(np.int64)[:, None] << 8) + np.arange(256)[None, :]
+    row, col = key >> t.width_bit, key & (t.width - 1)
+    idx = t.r[row] + col
+    ok = (idx >= 0) & (idx < t.ht_size)
+    idc = np.clip(idx, 0, t.ht_size - 1)
+    ok &= t.HT[idc] == row
+    return np.where(ok, t.val[idc], -1)
+
+
+def test_blob_round_trip_and_reference_arrays(resolve):
+    t = PfacTable.from_file(resolve("xad"), 1024)
+    blob = t.blob()
+    assert blob.dtype == np.int32 and blob[0] == 0x50464143
+    u = PfacTable.from_blob(blob)
+    for k in ("width", "width_bit", "n_patterns", "num_final", "state_num", "max_pat_len", "max_row", "ht_size", "n_keys"):
+        assert getattr(t, k) == getattr(u, k)
+    for k in ("s0", "r", "HT", "val", "idmap"):
+        assert (getattr(t, k) == getattr(u, k)).all()
+    with pytest.raises(PfacError):
+        PfacTable.from_blob(blob[:100])
+    bad = blob.copy(); bad[0] = 1
+    with pytest.raises(PfacError):
+        PfacTable.from_blob(bad)
+    # arrays as the reference's FFDM() leaves them (exact layout from the oracle's restatement)
+    o = Oracle(resolve("xad"), 1, 1)
+    o.ffdm(4096, exact=True)
+    st = o.stats()
+    L = o.L
+    w = PfacTable.from_reference_arrays(
+        o.trie()[st["final"] + 1], np.ctypeslib.as_array(L.orc_phf_r(o.m, 0), (st["r_size"],)),
+        np.ctypeslib.as_array(L.orc_phf_HT(o.m, 0), (st["ht_size"],)),
+        np.ctypeslib.as_array(L.orc_phf_val(o.m, 0), (st["ht_size"],)), o.idmap(), 4096, st["state_num"], st["final"],
+        st["ht_size"], L.orc_max_len(o.m))
+    assert (lookup_all(w) == o.trie()).all()
+    o.close()
+
+
+def test_reader_errors_are_reported_not_fatal(tmp_path):
+    """The reference exit(1)s (or runs into undefined behaviour) on these; the library returns PFAC_E_PATTERN / _ARG / _IO."""
+    def build(data, width=256):
+        return PfacTable.from_bytes(data, width)
+    with pytest.raises(PfacError) as e:
+        build(b"abc")                              # no trailing newline
+    assert e.value.status == -3
+    with pytest.raises(PfacError) as e:
+        build(b"abc\n\nde\n")                      # empty line
+    assert e.value.status == -3
+    with pytest.raises(PfacError) as e:
+        build(b"a" * 1024 + b"\n")                 # "Pattern 1 length over 1024."
+    assert e.value.status == -3 and "length over 1024" in str(e.value)
+    assert build(b"a" * 1023 + b"\n").max_pat_len == 1023
+    for w in (0, 3, 8192, -4):
+        with pytest.raises(PfacError) as e:
+            build(b"a\n", w)
+        assert e.value.status == -1
+    with pytest.raises(PfacError) as e:
+        PfacTable.from_file(str(tmp_path / "missing"), 256)
+    assert e.value.status == -2
+    t = build(b"b\r\n\xff\x00z\n")                 # \r kept, NUL and high bytes are ordinary pattern bytes
+    assert t.n_patterns == 2 and t.max_pat_len == 3
+
+
+def test_emitter_format(tmp_path, resolve):
+    from phfpfac_amd import RECORD_DTYPE, emit_records
+    rec = np.array([(4, 0), (12, 1), (9999, 0), (10000, 1), (4000000000, 0)], dtype=RECORD_DTYPE)
+    idmap = np.array([3, 77777], dtype=np.int32)
+    out = tmp_path / "o.txt"
+    n = emit_records(str(out), rec, idmap)
+    exp = "".join("At position %4d, match pattern %d\n" % (p, idmap[s]) for p, s in rec.tolist()).encode()
+    assert out.read_bytes() == exp and n == len(exp)
+    n2 = emit_records(str(out), rec[:2], idmap, base=(1 << 33), append=True)   # 64-bit positions, appended
+    tail = "".join("At position %4d, match pattern %d\n" % ((1 << 33) + p, idmap[s]) for p, s in rec[:2].tolist()).encode()
+    assert out.read_bytes() == exp + tail and n2 == len(tail)
