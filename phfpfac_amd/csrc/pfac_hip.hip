@@ -62,9 +62,12 @@ constexpr int LDS_TABLE_MAX = 40 * 1024;   // PHF tables up to this size are sta
 
 // shared (per workgroup) LDS: root row, 8 pre-shifted root-flag tables, then the PHF tables (variant 0)
 constexpr int SH_HDR = 0;                  // round rings (H_* below)
-constexpr int SH_S0 = SH_HDR + 1024;
+constexpr int SH_S0 = SH_HDR + 2048;
 constexpr int SH_FTAB = SH_S0 + 256 * 4;
-constexpr int SH_TAB = SH_FTAB + 8 * 256;
+constexpr int SH_D1IDX = SH_FTAB + 8 * 256; // 256 x u8: dense-row index of the depth-1 state reached on each root byte
+constexpr int SH_D1 = SH_D1IDX + 256;      // d1_rows dense rows int32[256] (the hot first-level transition rows)
+constexpr int D1_MAX = 32;                 // at most this many depth-1 states get a dense row (else none do)
+// the PHF tables (variant 0) follow the dense rows: SH_D1 + d1_rows * 1024
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
 constexpr int NBUF = 3;                    // staging buffers: a tile's records are emitted two rounds later
 constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
@@ -87,6 +90,10 @@ struct ScanArgs {
     int r_words, t_entries;
     int ht_size, wbit, num_final, halo;   // halo: bytes readable past a tile, multiple of 16
     int shared_bytes, pw_bytes;           // LDS carve: shared region, then one region per wave
+    const int *d1;                        // dense rows of the depth-1 states, d1_rows x 256 (or null)
+    const unsigned char *d1idx;           // root byte -> dense row index
+    int d1_rows;                          // 0: no dense level
+    int ablate;                           // PFAC_ABLATE (timing experiments only; results are wrong when != 0)
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
     unsigned stage_cap;                   // CAPW, or 0 when final states do not fit the packed staging word
     unsigned n_tiles;
@@ -142,10 +149,10 @@ constexpr int H_BATCH = 0;                 // batch id of round r
 constexpr int H_EPOCH = 8;                 // == r + 1 once H_BATCH (and a zeroed H_ARRIVED) are valid
 constexpr int H_ARRIVED = 16;              // compute waves that have posted their count
 constexpr int H_READY = 24;                // == r + 1 once H_GBASE is valid
-constexpr int H_GBASE = 32;                // 2 words per round: records before the batch
+constexpr int H_URGENT = 32;               // != 0: a wave of round r needs its base right away (staging overflow)
 constexpr int H_CNT = 48;                  // 16 words per round: match count of each compute wave
-constexpr int H_URGENT = H_CNT + RING * 16; // != 0: a wave of round r needs the batch base right away (staging overflow)
-constexpr int H_WORDS = H_URGENT + RING;
+constexpr int H_WBASE = H_CNT + RING * 16; // 32 words per round: {lo, hi} first record index of each compute wave
+constexpr int H_WORDS = H_WBASE + RING * 32;
 
 __device__ __forceinline__ unsigned lds_load(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -191,20 +198,36 @@ __device__ __forceinline__ void publish_aggregate(unsigned long long *status, un
 // published without waiting for anything, so every predecessor polled here belongs to a workgroup
 // that is running or done.
 constexpr int LB_WIN = 4;
+struct LbWindow {
+    unsigned long long st[LB_WIN];
+};
+// Issue the loads of the window right behind `tile` (no wait): the coordinator does this one round
+// before it needs the answer, so the memory round trip overlaps the next round's arrivals.
+__device__ __forceinline__ void lookback_issue(unsigned long long *status, unsigned tile, int lane, LbWindow &w) {
+#pragma unroll
+    for (int k = 0; k < LB_WIN; k++) {
+        const long long idx = (long long)tile - 1 - lane - WAVE * k;
+        w.st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
+    }
+}
+// pre != nullptr: the first window was loaded earlier by lookback_issue().
 __device__ unsigned long long lookback(unsigned long long *status, unsigned tile, unsigned long long tot, int lane,
-                                       unsigned *err) {
+                                       unsigned *err, const LbWindow *pre = nullptr) {
     if (tile == 0) return 0;
     unsigned long long excl = 0;
     long long top = (long long)tile - 1;              // nearest predecessor not yet accounted for
     unsigned spins = 0;
     bool failed = false;
+    bool use_pre = pre != nullptr;
     while (top >= 0) {
         unsigned long long st[LB_WIN];
 #pragma unroll
         for (int k = 0; k < LB_WIN; k++) {
             const long long idx = top - lane - WAVE * k;   // position WAVE*k + lane behind `top`
-            st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
+            if (use_pre) st[k] = pre->st[k];
+            else st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
         }
+        use_pre = false;
         // first unpublished and first inclusive position in the window (wave-uniform)
         int pz = LB_WIN * WAVE, pi = LB_WIN * WAVE;
 #pragma unroll
@@ -262,13 +285,15 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 // divergent branches -- far fewer exec-mask / scalar instructions per step.  Input bytes come four
 // at a time from one aligned 8-byte LDS read, so a step's only dependent LDS accesses are R and T.
 template <bool W8>
-__device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s0, const int *R, const int2 *T,
+__device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s0, const unsigned char *d1idx,
+                                         const int *D1, bool dense1, const int *R, const int2 *T,
                                          unsigned pos, bool active, unsigned lim, int wbit, int ht_size,
                                          int num_final, unsigned &m0, unsigned &m1) {
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
     unsigned lo = t32[pos >> 2], hi = t32[(pos >> 2) + 1];     // may run a few bytes past lim: never used
     unsigned win = __builtin_amdgcn_alignbyte(hi, lo, pos & 3u);   // bytes pos .. pos+3
     int s = s0[win & 0xFFu];
+    const unsigned f = d1idx[win & 0xFFu];                     // dense row of that state (when dense1)
     s = active ? s : -1;
     unsigned n = 0, p = pos + 1;
     bool go = false;
@@ -300,7 +325,14 @@ __device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s
         p++;
     };
     if (!reached()) return n;
-    step((win >> 8) & 0xFFu);
+    if (dense1) {
+        // second byte: the depth-1 state's row is dense in LDS -- one lookup, no hash, no owner check
+        const int nx = D1[(go ? f : 0u) * 256u + ((win >> 8) & 0xFFu)];
+        s = go ? nx : -1;
+        p++;
+    } else {
+        step((win >> 8) & 0xFFu);
+    }
     if (!reached()) return n;
     step((win >> 16) & 0xFFu);
     if (!reached()) return n;
@@ -354,17 +386,26 @@ __device__ __forceinline__ void walk_store(const unsigned char *tile, const int 
 
 // One round: up to 64 survivors (one per lane, in position order) are walked; their records are
 // appended at index `wrun` of the staging buffer (DIRECT == false) or of the global record array.
+struct Dense1 {
+    const unsigned char *idx;
+    const int *rows;
+    bool on;
+};
+
 template <bool W8, bool DIRECT>
-__device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned char *tile, const int *s0, const int *R,
+__device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
+                                            const int *R,
                                             const int2 *T, const unsigned short *q, unsigned qi, bool active,
                                             unsigned *stage, unsigned lim, unsigned long long tile_base,
                                             unsigned long long wrun) {
     unsigned m0 = 0, m1 = 0;
     const unsigned pos = active ? q[qi] : 0u;
-    const unsigned n = walk<W8>(tile, s0, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
+    unsigned n;
+    if (a.ablate & 2) { n = active ? 1u : 0u; m0 = pos & 3u; }
+    else n = walk<W8>(tile, s0, d1.idx, d1.rows, d1.on, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
     const unsigned inc = wave_incl_scan(n);
-    const unsigned long long ri = wrun + (inc - n);
     if (DIRECT) {
+        const unsigned long long ri = wrun + (inc - n);
         pfac_record rec;
         rec.pos = (unsigned)(tile_base + pos);
         if (n > 0 && ri < a.out_cap) { rec.state = m0; a.out[ri] = rec; }
@@ -372,6 +413,7 @@ __device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned ch
         if (n > 2)
             walk_store<W8, true>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, nullptr, 0, a.out, a.out_cap, ri, rec.pos);
     } else {
+        const unsigned ri = (unsigned)wrun + (inc - n);        // tile-local record index: 32 bits are plenty
         if (n > 0 && ri < a.stage_cap) stage[ri] = pos | (m0 << 12);
         if (n > 1 && ri + 1 < a.stage_cap) stage[ri + 1] = pos | (m1 << 12);
         if (n > 2)
@@ -386,7 +428,7 @@ __device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned ch
 // count; with DIRECT the records are written at global index wrun onwards.
 template <bool W8, bool DIRECT>
 __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
-                                                        const int *R, const int2 *T, unsigned short *q,
+                                                        const Dense1 &d1, const int *R, const int2 *T, unsigned short *q,
                                                         unsigned *stage, const unsigned (&masks)[SUBS], int lane,
                                                         unsigned lim, unsigned long long tile_base,
                                                         unsigned long long wrun) {
@@ -405,7 +447,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
         wave_lds_sync();
         unsigned h = 0;
         for (; h + WAVE <= tail; h += WAVE)
-            wrun += round64<W8, DIRECT>(a, tile, s0, R, T, q, h + lane, true, stage, lim, tile_base, wrun);
+            wrun += round64<W8, DIRECT>(a, tile, s0, d1, R, T, q, h + lane, true, stage, lim, tile_base, wrun);
         if (h) {                               // move the < 64 left-overs to the front
             const unsigned rem = tail - h;
             unsigned short v = 0;
@@ -416,7 +458,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             tail = rem;
         }
     }
-    if (tail) wrun += round64<W8, DIRECT>(a, tile, s0, R, T, q, lane, (unsigned)lane < tail, stage, lim, tile_base, wrun);
+    if (tail) wrun += round64<W8, DIRECT>(a, tile, s0, d1, R, T, q, lane, (unsigned)lane < tail, stage, lim, tile_base, wrun);
     return wrun;
 }
 
@@ -486,11 +528,21 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
 #pragma unroll
         for (int k = 0; k < 8; k++) ftab[k * 256 + i] = v >= 0 ? (unsigned char)(1u << k) : (unsigned char)0;
     }
+    unsigned char *d1idx_l = smem + SH_D1IDX;
+    int *d1_l = reinterpret_cast<int *>(smem + SH_D1);
+    if (a.d1_rows > 0) {
+        for (int i = tid; i < 256; i += blockDim.x) d1idx_l[i] = a.d1idx[i];
+        for (int i = tid; i < a.d1_rows * 256; i += blockDim.x) d1_l[i] = a.d1[i];
+    } else {
+        for (int i = tid; i < 256; i += blockDim.x) d1idx_l[i] = 0;
+    }
+    const Dense1 d1 = {d1idx_l, d1_l, a.d1_rows > 0};
+    const int sh_tab = SH_D1 + a.d1_rows * 1024;
     const int *R = a.r;
     const int2 *T = a.T;
     if (TLDS) {
-        int *lr = reinterpret_cast<int *>(smem + SH_TAB);
-        int2 *lt = reinterpret_cast<int2 *>(smem + SH_TAB + ((a.r_words * 4 + 15) & ~15));
+        int *lr = reinterpret_cast<int *>(smem + sh_tab);
+        int2 *lt = reinterpret_cast<int2 *>(smem + sh_tab + ((a.r_words * 4 + 15) & ~15));
         for (int i = tid; i < a.r_words; i += blockDim.x) lr[i] = a.r[i];
         for (int i = tid; i < a.t_entries; i += blockDim.x) lt[i] = a.T[i];
         R = lr;
@@ -500,6 +552,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
 
     if (wave == nc) {
         // ================= coordinator =================
+        __builtin_amdgcn_s_setprio(3);         // tiny, latency-critical instruction stream
         auto take_batch = [&](unsigned r) -> unsigned {     // ticket for round r -> ring, returns batch id
             unsigned g = 0;
             if (lane == 0) {
@@ -518,19 +571,28 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         // by then every batch of the same generation has published its aggregate, so it costs one
         // memory round trip instead of a wait for the slowest workgroup; the compute waves emit two
         // rounds late and never notice.
-        bool pend = false;                     // round r-1 still needs its look-back
-        unsigned pend_r = 0, pend_g = 0;
-        unsigned long long pend_tot = 0, pend_end = 0;
-        auto resolve = [&](unsigned rr, unsigned g, unsigned long long tot, unsigned long long end_tile) {
-            const unsigned long long excl = lookback(a.status, g, tot, lane, err);
+        // Rounds in flight in the coordinator: round r (waiting for its counts), round r-1 (aggregate
+        // published, look-back window loads just issued) and round r-2 (window loads issued one round
+        // ago -> finished from registers now).
+        struct Pend { bool on; unsigned r, g; unsigned long long tot, end; unsigned cnt; };
+        Pend p1 = {false, 0, 0, 0, 0, 0}, p2 = {false, 0, 0, 0, 0, 0};
+        LbWindow win = {};
+        // resolve a round: batch base from the look-back, then every compute wave's first record index
+        auto resolve = [&](const Pend &p, const LbWindow *pre) {
+            const unsigned long long excl = lookback(a.status, p.g, p.tot, lane, err, pre);
+            // exclusive prefix of the waves' counts (lane c holds wave c's count)
+            const unsigned incl = wave_incl_scan(p.cnt);
+            const unsigned long long wb = excl + (incl - p.cnt);
+            if (lane < nc) {
+                hdr[H_WBASE + (p.r & 7) * 32 + lane * 2] = (unsigned)wb;
+                hdr[H_WBASE + (p.r & 7) * 32 + lane * 2 + 1] = (unsigned)(wb >> 32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) {
-                hdr[H_GBASE + (rr & 7) * 2] = (unsigned)excl;
-                hdr[H_GBASE + (rr & 7) * 2 + 1] = (unsigned)(excl >> 32);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                lds_store(&hdr[H_READY + (rr & 7)], rr + 1);
-                if (end_tile >= a.n_tiles) {                // this batch holds the last tile: grand total
-                    a.ctl[2] = (unsigned)(excl + tot);
-                    a.ctl[3] = (unsigned)((excl + tot) >> 32);
+                lds_store(&hdr[H_READY + (p.r & 7)], p.r + 1);
+                if (p.end >= a.n_tiles) {                   // this batch holds the last tile: grand total
+                    a.ctl[2] = (unsigned)(excl + p.tot);
+                    a.ctl[3] = (unsigned)((excl + p.tot) >> 32);
                 }
             }
         };
@@ -541,6 +603,9 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             const bool trace = a.dbg && blockIdx.x < 8 && r < 64 && lane == 0;
             unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + r) * 32;
             if (trace) tr[0] = __builtin_amdgcn_s_memrealtime();
+            // (a) round r-2: its window loads were issued a whole round ago
+            if (p2.on) { resolve(p2, &win); p2.on = false; }
+            // (b) round r: wait for the counts, publish the aggregate
             const unsigned long long left = a.n_tiles - first;
             const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
             if (!lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
@@ -548,17 +613,21 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
             const unsigned long long tot = wave_sum64(c);
             publish_aggregate(a.status, g_cur, tot, lane);
-            if (pend) resolve(pend_r, pend_g, pend_tot, pend_end);
-            pend = true; pend_r = r; pend_g = g_cur; pend_tot = tot; pend_end = first + n_valid;
+            const Pend cur = {true, r, g_cur, tot, first + n_valid, c};
+            // (c) round r-1 moves on: issue its look-back window now, finish it next iteration
+            if (p1.on) { lookback_issue(a.status, p1.g, lane, win); p2 = p1; p1.on = false; }
+            p1 = cur;
             if (lds_load(&hdr[H_URGENT + (r & 7)]) != 0) {  // a wave overflowed its staging: it is waiting for this base
-                resolve(pend_r, pend_g, pend_tot, pend_end);
-                pend = false;
+                if (p2.on) { resolve(p2, &win); p2.on = false; }
+                resolve(p1, nullptr);
+                p1.on = false;
             }
             if (trace) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = g_cur; }
             g_cur = g_nxt;
             g_nxt = g_nxt2;
         }
-        if (pend) resolve(pend_r, pend_g, pend_tot, pend_end);
+        if (p2.on) resolve(p2, &win);
+        if (p1.on) resolve(p1, nullptr);
         return;
     }
 
@@ -581,12 +650,10 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         for (int j = 0; j < SUBS; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, j * SUB + lane * 16, 0, 0);
         if (lane * 16 < a.halo) hw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, WTILE + lane * 16, 0, 0);
     };
-    // record base of this wave's tile of round rr: batch base + counts of the waves before it
+    // first record index of this wave's tile of round rr (computed by the coordinator)
     auto record_base = [&](unsigned rr, unsigned long long &base) -> bool {
         if (!lds_wait_eq(&hdr[H_READY + (rr & 7)], rr + 1, err, 8u)) return false;
-        const unsigned long long g = ((unsigned long long)hdr[H_GBASE + (rr & 7) * 2 + 1] << 32) | hdr[H_GBASE + (rr & 7) * 2];
-        const unsigned c = lane < wave ? hdr[H_CNT + (rr & 7) * 16 + lane] : 0u;
-        base = g + wave_sum64(c);
+        base = ((unsigned long long)hdr[H_WBASE + (rr & 7) * 32 + wave * 2 + 1] << 32) | hdr[H_WBASE + (rr & 7) * 32 + wave * 2];
         return true;
     };
 
@@ -646,29 +713,37 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * CAPW;
-        const unsigned long long cnt = tile_pass<W8, false>(a, tile, s0, R, T, q, stage, masks, lane, lim, tile_base, 0);
+        if (a.ablate & 8) { masks[0] = masks[1] = masks[2] = masks[3] = (masks[0] & 1u) << 20; }
+        const unsigned long long cnt = (a.ablate & 1) ? (unsigned long long)(masks[0] >> 31)
+                                                      : tile_pass<W8, false>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
         if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
         const bool overflow = cnt > a.stage_cap;
+        unsigned arrival = 0;
         if (lane == 0) {
             hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
             if (overflow) lds_store(&hdr[H_URGENT + (r & 7)], 1u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            atomicAdd(&hdr[H_ARRIVED + (r & 7)], 1u);
+            arrival = atomicAdd(&hdr[H_ARRIVED + (r & 7)], 1u);
         }
+        // The SIMD arbitrates VALU issue by priority, then age, so the youngest wave of each SIMD falls
+        // behind and everybody ends up waiting for it.  Waves that arrived in the later half of this round
+        // run the next one at raised priority: the laggards catch up, the round time approaches the mean.
+        if (__builtin_amdgcn_readfirstlane(arrival) * 2u >= (unsigned)nc) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
 
         if (overflow) {
             // staging overflowed (or the automaton is too large for packed staging): emit this tile
             // now, while its bytes are still in LDS -- wait for the batch base, walk again to global
             unsigned long long base = 0;
-            if (record_base(r, base)) tile_pass<W8, true>(a, tile, s0, R, T, q, stage, masks, lane, lim, tile_base, base);
+            if (record_base(r, base)) tile_pass<W8, true>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
         }
         // ---- emit the tile of TWO rounds ago: its batch base has long been resolved
         if (have2) {
             unsigned long long base = 0;
             const bool okb = record_base(r - 2, base);
             if (trace) tr[9] = __builtin_amdgcn_s_memrealtime();
-            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
+            if (okb && !(a.ablate & 4)) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
         }
         if (trace) tr[8] = __builtin_amdgcn_s_memrealtime();
         have2 = have1; cnt2 = cnt1; t2 = t1;
@@ -706,6 +781,21 @@ __global__ void pfac_repack_kernel(const int *blob, int *s0, int *r, int2 *T, in
     for (int i = i0; i < max_row; i += stride) r[i] = b_r[i];
     for (int i = i0; i < ht_size; i += stride) T[i] = make_int2(b_HT[i], b_val[i]);
     for (int i = i0; i < num_final; i += stride) idmap[i] = b_id[i];
+}
+
+// Dense rows of the depth-1 states: row f, column c = lookup(state d1state[f], byte c) through the PHF.
+__global__ void pfac_build_d1_kernel(const int *d1state, const int *r, const int2 *T, int wbit, int ht_size, int *d1) {
+    const int st = d1state[blockIdx.x];
+    const int c = threadIdx.x;
+    const int key = (st << 8) | c;
+    const int row = key >> wbit;
+    const int idx = r[row] + (key & ((1 << wbit) - 1));
+    int nx = -1;
+    if ((unsigned)idx < (unsigned)ht_size) {
+        const int2 e = T[idx];
+        if (e.x == row) nx = e.y;
+    }
+    d1[blockIdx.x * 256 + c] = nx;
 }
 
 __device__ __forceinline__ unsigned long long match_hash(unsigned long long pos, unsigned id) {
@@ -796,6 +886,8 @@ struct pfac_ctx {
     const void *kernel = nullptr;
     int lds_bytes = 0, shared_bytes = 0, pw_bytes = 0, halo = 0, waves_per_block = 0, root_mode = 0;
     unsigned root_byte = 0, stage_cap = 0;
+    int *d_d1 = nullptr;                  // dense depth-1 rows + (after them) the 256-byte row index
+    int d1_rows = 0;
     int grid_blocks = 0;
     std::string err;
     std::mutex mu;
@@ -841,7 +933,28 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     if (getenv("PFAC_FORCE_L2")) ctx->variant = 1;             // tuning knob: tables via L2 even if they fit LDS
     int halo = ctx->max_pat_len > 1 ? ctx->max_pat_len - 1 : 0;
     ctx->halo = (halo + 15) & ~15;
-    ctx->shared_bytes = SH_TAB + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : 0);
+    // dense rows for the depth-1 states (children of the root), when there are few enough of them
+    int fan = 0, rb = 0;
+    int d1state[256];
+    unsigned char d1idx[256];
+    for (int i = 0; i < 256; i++) {
+        d1idx[i] = 0;
+        if (s0_host[i] >= 0) { d1state[fan] = s0_host[i]; d1idx[i] = (unsigned char)(fan < 255 ? fan : 255); fan++; rb = i; }
+    }
+    ctx->d1_rows = (fan >= 1 && fan <= D1_MAX && !getenv("PFAC_NO_D1")) ? fan : 0;
+    if (ctx->d_d1) { HIP_TRY(ctx, hipFree(ctx->d_d1)); ctx->d_d1 = nullptr; }
+    if (ctx->d1_rows) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_d1, (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4));
+        unsigned char *b = reinterpret_cast<unsigned char *>(ctx->d_d1);
+        int *d_state = reinterpret_cast<int *>(b + (size_t)ctx->d1_rows * 1024 + 256);
+        HIP_TRY(ctx, hipMemcpy(b + (size_t)ctx->d1_rows * 1024, d1idx, 256, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(d_state, d1state, (size_t)ctx->d1_rows * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pfac_build_d1_kernel, dim3(ctx->d1_rows), dim3(256), 0, 0, d_state, ctx->d_r, ctx->d_T,
+                           ctx->width_bit, ctx->ht_size, ctx->d_d1);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipDeviceSynchronize());
+    }
+    ctx->shared_bytes = SH_D1 + ctx->d1_rows * 1024 + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : 0);
     ctx->pw_bytes = (int)align_up((size_t)PW_FIXED + ctx->halo, 16);
     int nwb = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes + 1;     // compute waves + the coordinator (no LDS region)
     if (nwb > MAX_WAVES_PER_BLOCK) nwb = MAX_WAVES_PER_BLOCK;
@@ -853,8 +966,6 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     if (ctx->lds_bytes < LDS_TOTAL / 2 + 256) ctx->lds_bytes = LDS_TOTAL / 2 + 256;
     ctx->grid_blocks = ctx->n_cu;
     // root fan-out 1 -> exact SWAR root test (ROOT = 1), else LDS flag tables (ROOT = 0)
-    int fan = 0, rb = 0;
-    for (int i = 0; i < 256; i++) if (s0_host[i] >= 0) { fan++; rb = i; }
     ctx->root_mode = fan == 1 ? 1 : 0;
     ctx->root_byte = (unsigned)rb * 0x01010101u;
     ctx->stage_cap = ctx->num_final <= (1 << PACK_STATE_BITS) ? (unsigned)CAPW : 0u;
@@ -960,6 +1071,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
         if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
     }
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->d_d1) (void)hipFree(ctx->d_d1);
     delete ctx;
 }
 
@@ -1067,6 +1179,9 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
         a.halo = ctx->halo;
         a.shared_bytes = ctx->shared_bytes; a.pw_bytes = ctx->pw_bytes;
+        a.ablate = getenv("PFAC_ABLATE") ? atoi(getenv("PFAC_ABLATE")) : 0;
+        a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows;
+        a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte; a.stage_cap = ctx->stage_cap;
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = s.d_ctl;
