@@ -433,12 +433,33 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
                                                         unsigned lim, unsigned long long tile_base,
                                                         unsigned long long wrun) {
     unsigned tail = 0;                         // pending survivors, always < 64 between sub-tiles
+    // per-lane survivor counts of the 4 sub-tiles, prefix-summed two at a time (16-bit fields: a
+    // sub-tile holds at most 1024 survivors); the two independent DPP chains fill each other's wait states
+    static_assert(SUBS == 4, "packed scans assume 4 sub-tiles");
+    const unsigned c0 = __popc(masks[0]), c1 = __popc(masks[1]), c2 = __popc(masks[2]), c3 = __popc(masks[3]);
+    unsigned pa = c0 | (c1 << 16), pb = c2 | (c3 << 16);
+    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x111, 0xf, 0xf, false);
+    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x111, 0xf, 0xf, false);
+    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x112, 0xf, 0xf, false);
+    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x112, 0xf, 0xf, false);
+    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x114, 0xf, 0xf, false);
+    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x114, 0xf, 0xf, false);
+    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x118, 0xf, 0xf, false);
+    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x118, 0xf, 0xf, false);
+    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x142, 0xa, 0xf, false);
+    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x142, 0xa, 0xf, false);
+    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x143, 0xc, 0xf, false);
+    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x143, 0xc, 0xf, false);
+    const unsigned incls[SUBS] = {pa & 0xFFFFu, pa >> 16, pb & 0xFFFFu, pb >> 16};
+    const unsigned cnts[SUBS] = {c0, c1, c2, c3};
+    const unsigned la = bcast_last(pa), lb = bcast_last(pb);
+    const unsigned totals[SUBS] = {la & 0xFFFFu, la >> 16, lb & 0xFFFFu, lb >> 16};
 #pragma unroll
     for (int j = 0; j < SUBS; j++) {
         const unsigned mask = masks[j];
-        const unsigned cnt = __popc(mask);
-        const unsigned incl = wave_incl_scan(cnt);
-        const unsigned S = bcast_last(incl);
+        const unsigned cnt = cnts[j];
+        const unsigned incl = incls[j];
+        const unsigned S = totals[j];
         if (S == 0) continue;
         const unsigned lpos = j * SUB + lane * 16;
         unsigned o = tail + incl - cnt;
@@ -462,15 +483,32 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
     return wrun;
 }
 
-// Staged records of one tile -> global memory, in order.
+// Staged records of one tile -> global memory, in order.  Two records (16 bytes) per lane per store:
+// 8-byte-per-lane stores are issue-bound on CDNA (half the bytes per instruction).
 __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base,
                                          unsigned long long tile_base, int lane) {
-    for (unsigned i = lane; i < cnt; i += WAVE) {
-        const unsigned v = stage[i];
+    if (cnt == 0) return;
+    const unsigned tb = (unsigned)tile_base;                   // tile_base is a multiple of 4096
+    const unsigned head = (unsigned)(base & 1ull);             // odd first index: one single record keeps pairs 16-B aligned
+    if (head && lane == 0 && base < a.out_cap) {
+        const unsigned v = stage[0];
         pfac_record rec;
-        rec.pos = (unsigned)tile_base | (v & 0xFFFu);      // tile_base is a multiple of 4096
+        rec.pos = tb | (v & 0xFFFu);
         rec.state = v >> 12;
-        if (base + i < a.out_cap) a.out[base + i] = rec;
+        a.out[base] = rec;
+    }
+    for (unsigned i = head + 2u * (unsigned)lane; i < cnt; i += 2u * WAVE) {
+        const unsigned v0 = stage[i];
+        if (i + 1 < cnt && base + i + 1 < a.out_cap) {
+            const unsigned v1 = stage[i + 1];
+            u32x4 two = {tb | (v0 & 0xFFFu), v0 >> 12, tb | (v1 & 0xFFFu), v1 >> 12};
+            *reinterpret_cast<u32x4 *>(&a.out[base + i]) = two;
+        } else if (base + i < a.out_cap) {
+            pfac_record rec;
+            rec.pos = tb | (v0 & 0xFFFu);
+            rec.state = v0 >> 12;
+            a.out[base + i] = rec;
+        }
     }
 }
 
@@ -553,20 +591,26 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
     if (wave == nc) {
         // ================= coordinator =================
         __builtin_amdgcn_s_setprio(3);         // tiny, latency-critical instruction stream
-        auto take_batch = [&](unsigned r) -> unsigned {     // ticket for round r -> ring, returns batch id
+        // batch tickets: the atomic is ISSUED one iteration before its result is needed, so its ~1.3 us
+        // round trip never blocks the coordinator
+        auto ticket = [&]() -> unsigned {
             unsigned g = 0;
+            if (lane == 0) g = atomicAdd(&a.ctl[0], 1u);
+            return g;                          // valid in lane 0 (not waited for here)
+        };
+        auto publish_batch = [&](unsigned r, unsigned g_lane0) -> unsigned {   // ring entry of round r; returns batch id
             if (lane == 0) {
-                g = atomicAdd(&a.ctl[0], 1u);
                 lds_store(&hdr[H_ARRIVED + (r & 7)], 0u);
                 lds_store(&hdr[H_URGENT + (r & 7)], 0u);
-                lds_store(&hdr[H_BATCH + (r & 7)], g);
+                lds_store(&hdr[H_BATCH + (r & 7)], g_lane0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 lds_store(&hdr[H_EPOCH + (r & 7)], r + 1);
             }
-            return __builtin_amdgcn_readfirstlane(g);
+            return __builtin_amdgcn_readfirstlane(g_lane0);
         };
-        unsigned g_cur = take_batch(0);
-        unsigned g_nxt = take_batch(1);
+        unsigned g_cur = publish_batch(0, ticket());
+        unsigned g_nxt = publish_batch(1, ticket());
+        unsigned t_pending = ticket();         // for round 2, published at the top of iteration 0
         // The look-back of round r normally runs one round LATE (after round r+1's aggregate went out):
         // by then every batch of the same generation has published its aggregate, so it costs one
         // memory round trip instead of a wait for the slowest workgroup; the compute waves emit two
@@ -599,7 +643,8 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         for (unsigned r = 0;; r++) {
             const unsigned long long first = (unsigned long long)g_cur * (unsigned)nc;
             if (first >= a.n_tiles) break;     // batches are handed out in order: nothing left for this workgroup
-            const unsigned g_nxt2 = take_batch(r + 2);      // two rounds ahead of the compute waves
+            const unsigned g_nxt2 = publish_batch(r + 2, t_pending);   // two rounds ahead of the compute waves
+            t_pending = ticket();                           // for round r+3
             const bool trace = a.dbg && blockIdx.x < 8 && r < 64 && lane == 0;
             unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + r) * 32;
             if (trace) tr[0] = __builtin_amdgcn_s_memrealtime();
@@ -1160,6 +1205,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     if (((uintptr_t)in & 15) != 0) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: input pointer must be 16-byte aligned");
     if (n_owned > n_avail || n_owned > (1ull << 32)) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: need n_owned <= n_avail and n_owned <= 2^32");
     if (!d_input && n_avail > s.input_cap) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: n_avail exceeds the reserved input buffer");
+    if (((uintptr_t)d_records & 15) != 0) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: record buffer must be 16-byte aligned");
     if (!d_records && capacity) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: no record buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t n_tiles = (n_owned + WTILE - 1) / WTILE;

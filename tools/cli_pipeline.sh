@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU box: end-to-end gphf runs (H2D + scan + D2H + emit) on a generated 1 GiB text file: PCIe-inclusive rate.
+set -e
+cd "$(dirname "$0")/.."
+D=tests/golden/data
+W=$(mktemp -d)
+python3 - "$W" <<'PY'
+import sys, os
+para = open("tests/golden/data/paragraph402","rb").read()
+n = 1 << 30
+with open(os.path.join(sys.argv[1], "text1g"), "wb") as f:
+    blk = (para * (1 + (1 << 24) // 402))
+    # keep the 402-byte phase continuous across blocks
+    off = 0
+    while off < n:
+        k = min(1 << 24, n - off)
+        ph = off % 402
+        f.write((para[ph:] + blk)[:k])
+        off += k
+    f.write(b"\n")
+PY
+for s in 1 4; do
+  for p in bytefile_10000byte experimentpattern; do
+    ( cd $W && /usr/bin/time -f "wall %e s" $OLDPWD/phfpfac_amd/bin/gphf $OLDPWD/$D/$p $s 256 $W/text1g | grep -E "^2\.|^3\.|^4\." ; ls -la GPU_match_result.txt | awk '{print "output bytes", $5}' ) 2>&1 | sed "s/^/[$p streams=$s] /"
+  done
+done
+rm -rf $W
