@@ -106,8 +106,12 @@ def main():
         sys.exit("bench.py needs a GPU: the PFAC scan has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PFAC_BENCH_FORCE_DIST=1 runs the RCCL code path (table broadcast, count all-gather) even with one rank
+    use_dist = world > 1 or os.environ.get("PFAC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import tempfile
@@ -120,7 +124,7 @@ def main():
         pat_name, kind, desc = WORKLOADS[name]
         ppath = pattern_path(pat_name, tmpdir)
         g = GpuMatcher(local_rank, 1)
-        if world > 1:
+        if use_dist:
             table = PfacTable.from_file(ppath, 256) if rank == 0 else None
             blob, table = pdist.broadcast_table(table, dev, 0)             # RCCL broadcast of the table image
             torch.cuda.synchronize()
@@ -156,28 +160,37 @@ def main():
         if not ok:
             raise SystemExit(f"rank {rank}: PARITY FAILURE on workload {name}: first {k} records differ from the oracle")
 
+        pending = []
+
         def step():
             g.scan_async(n_owned, n_avail, d_input=buf)
             cnt, _ = g.scan_finish(0)
-            if world > 1:
-                pdist.gather_counts(cnt, dev)
+            if use_dist:                       # record-placement exchange: overlaps the next scan
+                pending.append(pdist.gather_counts_async(cnt, dev))
             return cnt
+
+        def drain():
+            for work, _ in pending:
+                work.wait()
+            pending.clear()
 
         for _ in range(warmup):
             step()
+        drain()
         kern_ms = []
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             cnt = step()
             kern_ms.append(g.elapsed_ms(0))
+        drain()                                # every count exchange of the K steps has completed
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -235,7 +248,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(res["ppath"], res["kind"], para)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

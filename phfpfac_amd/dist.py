@@ -78,6 +78,16 @@ def gather_counts(n_local: int, device: torch.device) -> List[int]:
     return [int(p.item()) for p in parts]
 
 
+def gather_counts_async(n_local: int, device: torch.device):
+    """Non-blocking form: returns (work, tensor of world int64 counts).  The exchange only places records, so a
+    scan loop can overlap it with the next scan and ``work.wait()`` when the offsets are needed."""
+    world = dist.get_world_size()
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    out = torch.empty(world, dtype=torch.int64, device=device)
+    work = dist.all_gather_into_tensor(out, mine, async_op=True)
+    return work, out
+
+
 def gather_records(records: torch.Tensor, n_local: int, counts: List[int], dst: int = 0) -> Optional[torch.Tensor]:
     """Ordered gather of compact records to rank ``dst``.
 

@@ -282,3 +282,40 @@ def test_errors_are_loud(resolve):
             g.scan_async(16)                                   # scan before a table upload
     with pytest.raises(PfacError):
         GpuMatcher(99, 1)                                      # no such device
+
+
+def test_rccl_path_single_rank(resolve):
+    """The N>1 plumbing on the real backend ("nccl" == RCCL) with one rank: table image broadcast into device
+    memory, pfac_table_upload_device, scan into a torch-owned record buffer, count all-gather, ordered gather."""
+    import torch
+    import torch.distributed as dist
+    from phfpfac_amd import dist as pdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        table = PfacTable.from_file(resolve("xaa"), 256)
+        blob, table2 = pdist.broadcast_table(table, dev, 0)
+        torch.cuda.synchronize()
+        data = np.frombuffer(open(resolve("1M"), "rb").read()[:150001], dtype=np.uint8)
+        n_total = data.size
+        lo, hi, end = pdist.shard_read_range(n_total, 0, 1, table2.halo)
+        buf = torch.zeros(end - lo + 64, dtype=torch.uint8, device=dev)
+        buf[: end - lo] = torch.from_numpy(data[lo:end].copy()).to(dev)
+        rec_t = torch.empty(1 << 17, dtype=torch.int64, device=dev)       # 8-byte records, torch-owned
+        with GpuMatcher(0, 1) as g:
+            g.load_table_device(blob, blob.numel(), 0, host_table=table2)
+            g.scan_async(hi - lo, end - lo, d_input=buf, d_records=rec_t, capacity=rec_t.numel())
+            n, over = g.scan_finish(0)
+            assert not over
+        counts = pdist.gather_counts(n, dev)
+        assert counts == [n]
+        gathered = pdist.gather_records(rec_t, n, counts, dst=0)
+        got = pdist.split_gathered(gathered, counts, n_total, 1)
+    finally:
+        dist.destroy_process_group()
+    pos, ids = oracle_pairs(resolve("xaa"), data)
+    assert got.size == pos.size
+    np.testing.assert_array_equal(got["pos"].astype(np.int64), pos)
+    np.testing.assert_array_equal(table.idmap[got["state"]], ids)
