@@ -112,7 +112,7 @@ def hip_lib() -> C.CDLL:
     """libpfac_hip.so (the GPU path).  Raises OSError when it was not built."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIB_DIR, "libpfac_hip.so")
+        path = os.environ.get("PFAC_HIP_LIB") or os.path.join(LIB_DIR, "libpfac_hip.so")   # override: A/B tuning builds
         if not os.path.exists(path):
             raise OSError(f"{path} is missing: the HIP extension was not built and there is no CPU fallback "
                           f"(run __graft_entry__.build() or `make -C phfpfac_amd/csrc`)")

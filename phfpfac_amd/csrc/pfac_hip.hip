@@ -296,15 +296,17 @@ __device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s
     const unsigned f = d1idx[win & 0xFFu];                     // dense row of that state (when dense1)
     s = active ? s : -1;
     unsigned n = 0, p = pos + 1;
-    bool go = false;
-    // account for the state just reached; false when no lane of the wave can go on
+    bool go = false, seen = false;
+    // account for the state just reached; false when no lane of the wave can go on.
+    // m0 = the first final state met, m1 = the latest one (== the second when exactly two are met);
+    // final <=> (unsigned)s < num_final, which also rejects the dead state -1.
     auto reached = [&]() -> bool {
-        const bool alive = s >= 0;
-        const bool fin = alive && s < num_final;
-        m0 = (fin && n == 0) ? (unsigned)s : m0;               // selects, not an indexed pair (that would go to scratch)
-        m1 = (fin && n == 1) ? (unsigned)s : m1;
+        const bool fin = (unsigned)s < (unsigned)num_final;
+        m0 = (fin && !seen) ? (unsigned)s : m0;
+        m1 = fin ? (unsigned)s : m1;
+        seen = seen || fin;
         n += fin ? 1u : 0u;
-        go = alive && p < lim;
+        go = s >= 0 && p < lim;
         return __any(go);
     };
     // one transition on input byte ch (straight-line: dead lanes look up a harmless, valid slot)
@@ -353,7 +355,8 @@ __device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s
 }
 
 // Same walk for the rare offsets where more than two patterns start: every final state from the
-// third on goes to the LDS staging buffer (packed) or straight to global memory.
+// SECOND on goes to the LDS staging buffer (packed) or straight to global memory (the fast walk keeps
+// only the first and the latest final state).
 template <bool W8, bool DIRECT>
 __device__ __forceinline__ void walk_store(const unsigned char *tile, const int *s0, const int *R, const int2 *T,
                                            unsigned pos, unsigned lim, int wbit, int ht_size, int num_final,
@@ -364,7 +367,7 @@ __device__ __forceinline__ void walk_store(const unsigned char *tile, const int 
     unsigned p = pos + 1;
     while (s >= 0) {
         if (s < num_final) {
-            if (n >= 2) {
+            if (n >= 1) {                                      // record 0 (m0) is written by the caller
                 if (DIRECT) {
                     if (ri + n < out_cap) {
                         pfac_record rec;
@@ -409,13 +412,13 @@ __device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned ch
         pfac_record rec;
         rec.pos = (unsigned)(tile_base + pos);
         if (n > 0 && ri < a.out_cap) { rec.state = m0; a.out[ri] = rec; }
-        if (n > 1 && ri + 1 < a.out_cap) { rec.state = m1; a.out[ri + 1] = rec; }
+        if (n == 2 && ri + 1 < a.out_cap) { rec.state = m1; a.out[ri + 1] = rec; }
         if (n > 2)
             walk_store<W8, true>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, nullptr, 0, a.out, a.out_cap, ri, rec.pos);
     } else {
         const unsigned ri = (unsigned)wrun + (inc - n);        // tile-local record index: 32 bits are plenty
         if (n > 0 && ri < a.stage_cap) stage[ri] = pos | (m0 << 12);
-        if (n > 1 && ri + 1 < a.stage_cap) stage[ri + 1] = pos | (m1 << 12);
+        if (n == 2 && ri + 1 < a.stage_cap) stage[ri + 1] = pos | (m1 << 12);
         if (n > 2)
             walk_store<W8, false>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, stage, a.stage_cap, nullptr, 0, ri, 0);
     }
