@@ -93,7 +93,6 @@ struct ScanArgs {
     const int *d1;                        // dense rows of the depth-1 states, d1_rows x 256 (or null)
     const unsigned char *d1idx;           // root byte -> dense row index
     int d1_rows;                          // 0: no dense level
-    int ablate;                           // PFAC_ABLATE (timing experiments only; results are wrong when != 0)
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
     unsigned stage_cap;                   // CAPW, or 0 when final states do not fit the packed staging word
     unsigned n_tiles;
@@ -403,9 +402,7 @@ __device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned ch
                                             unsigned long long wrun) {
     unsigned m0 = 0, m1 = 0;
     const unsigned pos = active ? q[qi] : 0u;
-    unsigned n;
-    if (a.ablate & 2) { n = active ? 1u : 0u; m0 = pos & 3u; }
-    else n = walk<W8>(tile, s0, d1.idx, d1.rows, d1.on, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
+    const unsigned n = walk<W8>(tile, s0, d1.idx, d1.rows, d1.on, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
     const unsigned inc = wave_incl_scan(n);
     if (DIRECT) {
         const unsigned long long ri = wrun + (inc - n);
@@ -761,9 +758,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * CAPW;
-        if (a.ablate & 8) { masks[0] = masks[1] = masks[2] = masks[3] = (masks[0] & 1u) << 20; }
-        const unsigned long long cnt = (a.ablate & 1) ? (unsigned long long)(masks[0] >> 31)
-                                                      : tile_pass<W8, false>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
+        const unsigned long long cnt = tile_pass<W8, false>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
         if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
         const bool overflow = cnt > a.stage_cap;
@@ -791,7 +786,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             unsigned long long base = 0;
             const bool okb = record_base(r - 2, base);
             if (trace) tr[9] = __builtin_amdgcn_s_memrealtime();
-            if (okb && !(a.ablate & 4)) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
+            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
         }
         if (trace) tr[8] = __builtin_amdgcn_s_memrealtime();
         have2 = have1; cnt2 = cnt1; t2 = t1;
@@ -1228,7 +1223,6 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
         a.halo = ctx->halo;
         a.shared_bytes = ctx->shared_bytes; a.pw_bytes = ctx->pw_bytes;
-        a.ablate = getenv("PFAC_ABLATE") ? atoi(getenv("PFAC_ABLATE")) : 0;
         a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows;
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte; a.stage_cap = ctx->stage_cap;
