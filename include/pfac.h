@@ -113,6 +113,11 @@ typedef struct pfac_record {
     uint32_t state;     /* final state reached (== index into idmap) */
 } pfac_record;
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap);
+/* Same bytes, produced by n_threads host threads (size pass, prefix sum, format + pwrite in place); the serial
+ * fprintf loop is the end-to-end wall once the scan runs at TB/s.  The file must be seekable; falls back to the
+ * serial emitter for small n, n_threads < 2 or pipes. */
+int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
+                             int n_threads);
 
 /* ------------------------------------------------------------------ */
 /* Device side (libpfac_hip.so): the master_kernel.cu path.            */

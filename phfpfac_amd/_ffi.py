@@ -67,7 +67,7 @@ class CThreadData(C.Structure):
 HOST_SYMBOLS = (
     "pfac_table_build_file", "pfac_table_build_mem", "pfac_table_free", "pfac_table_lookup",
     "pfac_table_blob_words", "pfac_table_to_blob", "pfac_table_from_blob", "pfac_table_from_reference_arrays",
-    "pfac_emit_records",
+    "pfac_emit_records", "pfac_emit_records_mt",
 )
 HIP_SYMBOLS = (
     "pfac_device_count", "pfac_ctx_create", "pfac_ctx_destroy", "pfac_last_error", "pfac_table_upload",
@@ -104,6 +104,8 @@ def host_lib() -> C.CDLL:
         L.pfac_table_from_reference_arrays.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.POINTER(TP)]
         L.pfac_emit_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.pfac_emit_records.restype = C.c_int64
+        L.pfac_emit_records_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        L.pfac_emit_records_mt.restype = C.c_int64
         _host = L
     return _host
 

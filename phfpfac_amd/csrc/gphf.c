@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 typedef struct {
     uint64_t base;          /* global offset of the chunk's first owned byte */
@@ -200,11 +201,14 @@ int main(int argc, char *argv[]) {
     if (!fpout) { perror("Open output file failed.\n"); return 1; }
     uint64_t total = 0;
     double kernel_ms = 0;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    int emit_threads = ncpu > 16 ? 16 : (ncpu < 1 ? 1 : (int)ncpu);
+    if (getenv("PFAC_EMIT_THREADS")) emit_threads = atoi(getenv("PFAC_EMIT_THREADS"));
     for (int g = 0; g < n_gpu; g++) {                            /* shard order == position order */
         kernel_ms += ws[g].kernel_ms;
         for (int k = 0; k < ws[g].n_chunks; k++) {
             chunk_t *c = &ws[g].chunks[k];
-            if (pfac_emit_records(fpout, c->rec, c->n_rec, c->base, tab->idmap) < 0) { fprintf(stderr, "write failed\n"); return 1; }
+            if (pfac_emit_records_mt(fpout, c->rec, c->n_rec, c->base, tab->idmap, emit_threads) < 0) { fprintf(stderr, "write failed\n"); return 1; }
             total += c->n_rec;
             free(c->rec);
         }

@@ -29,9 +29,12 @@
  */
 #include "pfac.h"
 
+#include <fcntl.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define PFAC_MAX_PATTERN_LEN 1023   /* str[1024] with the '\n' (create_table_reorder.c:55,74) */
 #define PFAC_COL_MAX 4096           /* phf.c:8 */
@@ -436,5 +439,112 @@ int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64
         total += (int64_t)len;
     }
     free(buf);
+    return total;
+}
+
+/* ---- parallel text emitter (once the scan runs at TB/s the serial fprintf loop of
+ * main.cc:341-349 is the end-to-end wall).  Records are cut into blocks; pass 1 sizes every block (line
+ * length depends on the digit counts), a prefix sum gives each block its file offset, pass 2 formats the
+ * blocks and pwrite()s them in place from all threads.  Byte-identical to the serial emitter. ---- */
+enum { EMIT_BLOCK = 1 << 17, EMIT_LINE_MAX = 64 };
+
+static inline int ndigits(uint64_t v) {
+    int n = 1;
+    while (v >= 10) { v /= 10; n++; }
+    return n;
+}
+
+typedef struct {
+    const pfac_record *rec;
+    uint64_t n, base;
+    const int32_t *idmap;
+    uint64_t n_blocks;
+    uint64_t *block_bytes;          /* pass 1 out, then exclusive prefix = file offsets */
+    int fd;
+    int64_t file_base;
+    int pass;
+    int tid, n_threads;
+    int rc;
+} emit_job;
+
+static void *emit_worker(void *arg) {
+    emit_job *j = (emit_job *)arg;
+    char *buf = NULL;
+    if (j->pass == 2) {
+        buf = (char *)malloc((size_t)EMIT_BLOCK * EMIT_LINE_MAX);
+        if (!buf) { j->rc = PFAC_E_NOMEM; return NULL; }
+    }
+    for (uint64_t b = (uint64_t)j->tid; b < j->n_blocks; b += (uint64_t)j->n_threads) {
+        const uint64_t k0 = b * EMIT_BLOCK, k1 = k0 + EMIT_BLOCK < j->n ? k0 + EMIT_BLOCK : j->n;
+        if (j->pass == 1) {
+            uint64_t bytes = 0;
+            for (uint64_t k = k0; k < k1; k++) {
+                const int dp = ndigits(j->base + j->rec[k].pos);
+                const int32_t id = j->idmap[j->rec[k].state];
+                const int di = id < 0 ? 1 + ndigits((uint64_t)(-(int64_t)id)) : ndigits((uint64_t)id);
+                bytes += 12 + (uint64_t)(dp < 4 ? 4 : dp) + 16 + (uint64_t)di + 1;
+            }
+            j->block_bytes[b] = bytes;
+        } else {
+            char *p = buf;
+            for (uint64_t k = k0; k < k1; k++) {
+                memcpy(p, "At position ", 12); p += 12;
+                p = put_uint(p, j->base + j->rec[k].pos, 4);
+                memcpy(p, ", match pattern ", 16); p += 16;
+                const int32_t id = j->idmap[j->rec[k].state];
+                if (id < 0) { *p++ = '-'; p = put_uint(p, (uint64_t)(-(int64_t)id), 1); }
+                else p = put_uint(p, (uint64_t)id, 1);
+                *p++ = '\n';
+            }
+            size_t len = (size_t)(p - buf), done = 0;
+            const int64_t off = j->file_base + (int64_t)j->block_bytes[b];
+            while (done < len) {
+                ssize_t w = pwrite(j->fd, buf + done, len - done, off + (int64_t)done);
+                if (w <= 0) { j->rc = PFAC_E_IO; free(buf); return NULL; }
+                done += (size_t)w;
+            }
+        }
+    }
+    free(buf);
+    return NULL;
+}
+
+int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
+                             int n_threads) {
+    if (!file || (!rec && n) || !idmap) return PFAC_E_ARG;
+    if (n_threads < 2 || n < 4 * (uint64_t)EMIT_BLOCK) return pfac_emit_records(file, rec, n, base, idmap);
+    if (n_threads > 64) n_threads = 64;
+    FILE *f = (FILE *)file;
+    if (fflush(f)) return PFAC_E_IO;
+    const int fd = fileno(f);
+    const long at = ftell(f);
+    /* pipes are not seekable, and Linux pwrite() ignores the offset on O_APPEND descriptors: serial path */
+    if (fd < 0 || at < 0 || (fcntl(fd, F_GETFL) & O_APPEND)) return pfac_emit_records(file, rec, n, base, idmap);
+    const uint64_t n_blocks = (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
+    uint64_t *bb = (uint64_t *)malloc((size_t)n_blocks * sizeof(uint64_t));
+    emit_job *jobs = (emit_job *)calloc((size_t)n_threads, sizeof(emit_job));
+    pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    if (!bb || !jobs || !th) { free(bb); free(jobs); free(th); return PFAC_E_NOMEM; }
+    int64_t total = 0;
+    int rc = 0;
+    for (int pass = 1; pass <= 2 && !rc; pass++) {
+        for (int t = 0; t < n_threads; t++) {
+            emit_job j = {rec, n, base, idmap, n_blocks, bb, fd, (int64_t)at, pass, t, n_threads, 0};
+            jobs[t] = j;
+            if (pthread_create(&th[t], NULL, emit_worker, &jobs[t])) { jobs[t].rc = PFAC_E_NOMEM; emit_worker(&jobs[t]); th[t] = 0; }
+        }
+        for (int t = 0; t < n_threads; t++) {
+            if (th[t]) pthread_join(th[t], NULL);
+            if (jobs[t].rc) rc = jobs[t].rc;
+        }
+        if (pass == 1) {                            /* exclusive prefix: block sizes -> offsets */
+            uint64_t acc = 0;
+            for (uint64_t b = 0; b < n_blocks; b++) { uint64_t v = bb[b]; bb[b] = acc; acc += v; }
+            total = (int64_t)acc;
+        }
+    }
+    free(bb); free(jobs); free(th);
+    if (rc) return rc;
+    if (fseek(f, at + (long)total, SEEK_SET)) return PFAC_E_IO;
     return total;
 }

@@ -114,8 +114,10 @@ class PfacTable:
             self._ptr = None
 
 
-def emit_records(path_or_file, records: np.ndarray, idmap: np.ndarray, base: int = 0, append: bool = False) -> int:
-    """Write ``At position %4d, match pattern %d`` lines (main.cc:335-350).  Returns bytes written."""
+def emit_records(path_or_file, records: np.ndarray, idmap: np.ndarray, base: int = 0, append: bool = False,
+                 threads: int = 1) -> int:
+    """Write ``At position %4d, match pattern %d`` lines (main.cc:335-350).  Returns bytes written.
+    ``threads`` > 1 uses the parallel emitter (same bytes)."""
     L = host_lib()
     libc = C.CDLL(None)
     libc.fopen.restype = C.c_void_p
@@ -123,11 +125,18 @@ def emit_records(path_or_file, records: np.ndarray, idmap: np.ndarray, base: int
     libc.fclose.argtypes = [C.c_void_p]
     records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
     idmap = np.ascontiguousarray(idmap, dtype=np.int32)
-    f = libc.fopen(os.fsencode(path_or_file), b"ab" if append else b"wb")
+    libc.fseek.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    # append = open for update and seek to the end (an "a" stream is O_APPEND, which defeats positioned writes)
+    f = libc.fopen(os.fsencode(path_or_file), b"r+b" if append and os.path.exists(path_or_file) else b"wb")
     if not f:
         raise PfacError(-2, f"cannot open {path_or_file}")
+    if append:
+        libc.fseek(f, 0, 2)
     try:
-        n = L.pfac_emit_records(f, records.ctypes.data, records.size, int(base), idmap.ctypes.data)
+        if threads > 1:
+            n = L.pfac_emit_records_mt(f, records.ctypes.data, records.size, int(base), idmap.ctypes.data, int(threads))
+        else:
+            n = L.pfac_emit_records(f, records.ctypes.data, records.size, int(base), idmap.ctypes.data)
     finally:
         libc.fclose(f)
     if n < 0:

@@ -127,3 +127,20 @@ def test_emitter_format(tmp_path, resolve):
     n2 = emit_records(str(out), rec[:2], idmap, base=(1 << 33), append=True)   # 64-bit positions, appended
     tail = "".join("At position %4d, match pattern %d\n" % ((1 << 33) + p, idmap[s]) for p, s in rec[:2].tolist()).encode()
     assert out.read_bytes() == exp + tail and n2 == len(tail)
+
+
+def test_parallel_emitter_is_byte_identical(tmp_path):
+    """pfac_emit_records_mt (size pass + prefix + parallel pwrite) == the serial emitter, also when appending."""
+    from phfpfac_amd import RECORD_DTYPE, emit_records
+    rng = np.random.default_rng(5)
+    n = 700_000
+    rec = np.empty(n, dtype=RECORD_DTYPE)
+    rec["pos"] = np.sort(rng.integers(0, 2**32 - 1, n, dtype=np.uint64)).astype(np.uint32)
+    rec["state"] = rng.integers(0, 5000, n)
+    idmap = rng.integers(1, 2_000_000, 5000).astype(np.int32)
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    for base in (0, 1 << 33):
+        na = emit_records(str(a), rec, idmap, base=base, append=base != 0)
+        nb = emit_records(str(b), rec, idmap, base=base, append=base != 0, threads=5)
+        assert na == nb
+    assert a.read_bytes() == b.read_bytes()
