@@ -40,10 +40,17 @@ WORKLOADS = {
     "text1g_bytefile10000": ("bytefile_10000byte", "text", "bytefile/10000byte (1376 patterns) x reference 1M text tiled to 1 GiB/GPU"),
     "rand1g_experimentpattern": ("experimentpattern", "rand", "experimentpattern x splitmix64 random bytes, 1 GiB/GPU"),
     "text1g_dictionary": ("xaa+xab+xac+xad", "text", "7989-word dictionary (xaa..xad) x reference 1M text tiled to 1 GiB/GPU"),
+    "text1g_snort75k": ("bytefile_1000000byte.gz", "text", "bytefile/1000000byte (75840 patterns, 542732 states, tables via L2) x reference 1M text tiled to 1 GiB/GPU"),
 }
 
 
 def pattern_path(name, tmpdir):
+    if name.endswith(".gz"):
+        import gzip
+        p = os.path.join(tmpdir, name[:-3])
+        with gzip.open(os.path.join(DATA, name), "rb") as g, open(p, "wb") as f:
+            f.write(g.read())
+        return p
     if "+" not in name:
         return os.path.join(DATA, name)
     p = os.path.join(tmpdir, "all.pat")

@@ -50,7 +50,7 @@ constexpr int SUB = WAVE * 16;             // bytes one wave covers with one 16-
 constexpr int SUBS = 4;                    // such sub-tiles per wave tile
 constexpr int WTILE = SUB * SUBS;          // 4096: tile-local positions fit 12 bits
 constexpr int HALO_MAX = 1024;             // >= max_pat_len - 1 (patterns are < 1024 bytes), multiple of 16
-constexpr int QCAP = SUB + WAVE;           // survivor FIFO: < 64 carried over + up to 1024 appended
+constexpr int QCAP = SUB + 2 * WAVE;       // survivor FIFO: < 128 carried over + up to 1024 appended
 #ifndef PFAC_CAPW
 #define PFAC_CAPW 384
 #endif
@@ -278,78 +278,115 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
     return e.x == row ? e.y : -1;
 }
 
-// Walk from tile-local position `pos`; counts final states reached, keeps the first two in m0/m1.
-// lim = first tile-local byte that may not be read.  All 64 lanes step together (the trip count is
-// the deepest walk in the wave) and dead lanes are predicated with selects instead of nested
-// divergent branches -- far fewer exec-mask / scalar instructions per step.  Input bytes come four
-// at a time from one aligned 8-byte LDS read, so a step's only dependent LDS accesses are R and T.
-template <bool W8>
-__device__ __forceinline__ unsigned walk(const unsigned char *tile, const int *s0, const unsigned char *d1idx,
-                                         const int *D1, bool dense1, const int *R, const int2 *T,
-                                         unsigned pos, bool active, unsigned lim, int wbit, int ht_size,
-                                         int num_final, unsigned &m0, unsigned &m1) {
+// NWALK independent walks per lane, stepped together.  Walk w starts at tile-local position pos[w];
+// n[w] counts the final states reached, m0[w] keeps the first one, m1[w] the latest one (== the second
+// when exactly two are met).  lim = first tile-local byte that may not be read.
+//  * all lanes step in lock step (trip count = deepest walk in the wave); dead lanes are predicated with
+//    selects instead of nested divergent branches -- far fewer exec-mask / scalar instructions per step;
+//  * input bytes come four at a time from one aligned 8-byte LDS read, so a step's only dependent
+//    accesses are R and T (or one dense-row lookup for the second byte);
+//  * NWALK = 2 (tables gathered through L2): every table round trip has an independent twin in flight --
+//    the memory-level parallelism of twice the occupancy without the LDS more waves would need.  With
+//    the tables in LDS a second walk buys nothing (measured), so NWALK = 1 there.
+template <bool W8, int NWALK>
+__device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, const unsigned char *d1idx,
+                                      const int *D1, bool dense1, const int *R, const int2 *T,
+                                      const unsigned (&pos)[NWALK], const bool (&active)[NWALK], unsigned lim, int wbit,
+                                      int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m0)[NWALK],
+                                      unsigned (&m1)[NWALK]) {
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
-    unsigned lo = t32[pos >> 2], hi = t32[(pos >> 2) + 1];     // may run a few bytes past lim: never used
-    unsigned win = __builtin_amdgcn_alignbyte(hi, lo, pos & 3u);   // bytes pos .. pos+3
-    int s = s0[win & 0xFFu];
-    const unsigned f = d1idx[win & 0xFFu];                     // dense row of that state (when dense1)
-    s = active ? s : -1;
-    unsigned n = 0, p = pos + 1;
-    bool go = false, seen = false;
-    // account for the state just reached; false when no lane of the wave can go on.
-    // m0 = the first final state met, m1 = the latest one (== the second when exactly two are met);
+    unsigned win[NWALK], p[NWALK], f[NWALK];
+    int s[NWALK];
+    bool go[NWALK], seen[NWALK];
+#pragma unroll
+    for (int w = 0; w < NWALK; w++) {
+        const unsigned lo = t32[pos[w] >> 2], hi = t32[(pos[w] >> 2) + 1];   // may run a few bytes past lim: never used
+        win[w] = __builtin_amdgcn_alignbyte(hi, lo, pos[w] & 3u);          // bytes pos .. pos+3
+    }
+#pragma unroll
+    for (int w = 0; w < NWALK; w++) {
+        const int st = s0[win[w] & 0xFFu];
+        f[w] = d1idx[win[w] & 0xFFu];                          // dense row of that state (when dense1)
+        s[w] = active[w] ? st : -1;
+        n[w] = 0; m0[w] = 0; m1[w] = 0;
+        p[w] = pos[w] + 1;
+        go[w] = false; seen[w] = false;
+    }
+    // account for the states just reached; false when no lane of the wave can go on.
     // final <=> (unsigned)s < num_final, which also rejects the dead state -1.
     auto reached = [&]() -> bool {
-        const bool fin = (unsigned)s < (unsigned)num_final;
-        m0 = (fin && !seen) ? (unsigned)s : m0;
-        m1 = fin ? (unsigned)s : m1;
-        seen = seen || fin;
-        n += fin ? 1u : 0u;
-        go = s >= 0 && p < lim;
-        return __any(go);
-    };
-    // one transition on input byte ch (straight-line: dead lanes look up a harmless, valid slot)
-    auto step = [&](unsigned ch) {
-        const int sg = go ? s : 0;
-        int row, idx;
-        if (W8) {
-            row = sg;
-            idx = R[sg] + (int)ch;
-        } else {
-            const int key = (sg << 8) | (int)ch;
-            row = key >> wbit;
-            idx = R[row] + (key & ((1 << wbit) - 1));
+        bool any = false;
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) {
+            const bool fin = (unsigned)s[w] < (unsigned)num_final;
+            m0[w] = (fin && !seen[w]) ? (unsigned)s[w] : m0[w];
+            m1[w] = fin ? (unsigned)s[w] : m1[w];
+            seen[w] = seen[w] || fin;
+            n[w] += fin ? 1u : 0u;
+            go[w] = s[w] >= 0 && p[w] < lim;
+            any = any || go[w];
         }
-        const unsigned ic = min((unsigned)idx, (unsigned)ht_size - 1u);
-        const int2 e = T[ic];
-        s = (go && ic == (unsigned)idx && e.x == row) ? e.y : -1;
-        p++;
+        return __any(any);
     };
-    if (!reached()) return n;
+    // one transition on byte number `bi` of the window (straight-line: dead lanes look up a harmless, valid slot)
+    auto step = [&](int bi) {
+        int row[NWALK], idx[NWALK];
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) {
+            const int ch = (int)((win[w] >> (8 * bi)) & 0xFFu);
+            const int sg = go[w] ? s[w] : 0;
+            if (W8) {
+                row[w] = sg;
+                idx[w] = R[sg] + ch;
+            } else {
+                const int key = (sg << 8) | ch;
+                row[w] = key >> wbit;
+                idx[w] = R[row[w]] + (key & ((1 << wbit) - 1));
+            }
+        }
+        int2 e[NWALK];
+        unsigned ic[NWALK];
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) {
+            ic[w] = min((unsigned)idx[w], (unsigned)ht_size - 1u);
+            e[w] = T[ic[w]];
+        }
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) {
+            s[w] = (go[w] && ic[w] == (unsigned)idx[w] && e[w].x == row[w]) ? e[w].y : -1;
+            p[w]++;
+        }
+    };
+    if (!reached()) return;
     if (dense1) {
         // second byte: the depth-1 state's row is dense in LDS -- one lookup, no hash, no owner check
-        const int nx = D1[(go ? f : 0u) * 256u + ((win >> 8) & 0xFFu)];
-        s = go ? nx : -1;
-        p++;
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) {
+            const int nx = D1[(go[w] ? f[w] : 0u) * 256u + ((win[w] >> 8) & 0xFFu)];
+            s[w] = go[w] ? nx : -1;
+            p[w]++;
+        }
     } else {
-        step((win >> 8) & 0xFFu);
+        step(1);
     }
-    if (!reached()) return n;
-    step((win >> 16) & 0xFFu);
-    if (!reached()) return n;
-    step(win >> 24);
-    for (;;) {                                                 // deeper than 4 bytes: next aligned window
-        if (!reached()) return n;
-        lo = t32[p >> 2];
-        hi = t32[(p >> 2) + 1];
-        win = __builtin_amdgcn_alignbyte(hi, lo, p & 3u);
-        step(win & 0xFFu);
-        if (!reached()) return n;
-        step((win >> 8) & 0xFFu);
-        if (!reached()) return n;
-        step((win >> 16) & 0xFFu);
-        if (!reached()) return n;
-        step(win >> 24);
+    if (!reached()) return;
+    step(2);
+    if (!reached()) return;
+    step(3);
+    for (;;) {                                                 // deeper than 4 bytes: next aligned windows
+        if (!reached()) return;
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) {
+            const unsigned lo = t32[p[w] >> 2], hi = t32[(p[w] >> 2) + 1];
+            win[w] = __builtin_amdgcn_alignbyte(hi, lo, p[w] & 3u);
+        }
+        step(0);
+        if (!reached()) return;
+        step(1);
+        if (!reached()) return;
+        step(2);
+        if (!reached()) return;
+        step(3);
     }
 }
 
@@ -394,45 +431,64 @@ struct Dense1 {
     bool on;
 };
 
-template <bool W8, bool DIRECT>
-__device__ __forceinline__ unsigned round64(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
-                                            const int *R,
-                                            const int2 *T, const unsigned short *q, unsigned qi, bool active,
-                                            unsigned *stage, unsigned lim, unsigned long long tile_base,
-                                            unsigned long long wrun) {
-    unsigned m0 = 0, m1 = 0;
-    const unsigned pos = active ? q[qi] : 0u;
-    const unsigned n = walk<W8>(tile, s0, d1.idx, d1.rows, d1.on, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, m0, m1);
-    const unsigned inc = wave_incl_scan(n);
-    if (DIRECT) {
-        const unsigned long long ri = wrun + (inc - n);
-        pfac_record rec;
-        rec.pos = (unsigned)(tile_base + pos);
-        if (n > 0 && ri < a.out_cap) { rec.state = m0; a.out[ri] = rec; }
-        if (n == 2 && ri + 1 < a.out_cap) { rec.state = m1; a.out[ri + 1] = rec; }
-        if (n > 2)
-            walk_store<W8, true>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, nullptr, 0, a.out, a.out_cap, ri, rec.pos);
-    } else {
-        const unsigned ri = (unsigned)wrun + (inc - n);        // tile-local record index: 32 bits are plenty
-        if (n > 0 && ri < a.stage_cap) stage[ri] = pos | (m0 << 12);
-        if (n == 2 && ri + 1 < a.stage_cap) stage[ri + 1] = pos | (m1 << 12);
-        if (n > 2)
-            walk_store<W8, false>(tile, s0, R, T, pos, lim, a.wbit, a.ht_size, a.num_final, stage, a.stage_cap, nullptr, 0, ri, 0);
+// One round: up to 64*NWALK survivors -- queue entries [q0, q0+nact), lane L takes entries L, L+64, ... walked
+// side by side -- append their records, in queue (= position) order, at index `wrun` of the staging
+// buffer (DIRECT == false) or of the global record array.  Returns the number of records.
+template <bool W8, bool DIRECT, int NWALK>
+__device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
+                                           const int *R, const int2 *T, const unsigned short *q, unsigned q0,
+                                           unsigned nact, int lane, unsigned *stage, unsigned lim,
+                                           unsigned long long tile_base, unsigned long long wrun) {
+    static_assert(NWALK == 1 || NWALK == 2, "one or two walks per lane");
+    bool active[NWALK];
+    unsigned pos[NWALK], n[NWALK], m0[NWALK], m1[NWALK];
+#pragma unroll
+    for (int w = 0; w < NWALK; w++) {
+        active[w] = (unsigned)lane + WAVE * w < nact;
+        pos[w] = active[w] ? q[q0 + WAVE * w + lane] : 0u;
     }
-    return bcast_last(inc);
+    walkN<W8, NWALK>(tile, s0, d1.idx, d1.rows, d1.on, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, n, m0, m1);
+    // one prefix sum for both halves (16-bit fields; a walk reports < 1024 matches)
+    const unsigned packed = NWALK == 2 ? (n[0] | (n[NWALK - 1] << 16)) : n[0];
+    const unsigned inc = wave_incl_scan(packed);
+    const unsigned last = bcast_last(inc);
+    const unsigned tot0 = NWALK == 2 ? (last & 0xFFFFu) : last;
+    const unsigned tot1 = NWALK == 2 ? (last >> 16) : 0u;
+    unsigned ex[NWALK];
+    ex[0] = (NWALK == 2 ? (inc & 0xFFFFu) : inc) - n[0];
+    if (NWALK == 2) ex[NWALK - 1] = tot0 + (inc >> 16) - n[NWALK - 1];
+#pragma unroll
+    for (int w = 0; w < NWALK; w++) {
+        if (DIRECT) {
+            const unsigned long long ri = wrun + ex[w];
+            pfac_record rec;
+            rec.pos = (unsigned)(tile_base + pos[w]);
+            if (n[w] > 0 && ri < a.out_cap) { rec.state = m0[w]; a.out[ri] = rec; }
+            if (n[w] == 2 && ri + 1 < a.out_cap) { rec.state = m1[w]; a.out[ri + 1] = rec; }
+            if (n[w] > 2)
+                walk_store<W8, true>(tile, s0, R, T, pos[w], lim, a.wbit, a.ht_size, a.num_final, nullptr, 0, a.out, a.out_cap, ri, rec.pos);
+        } else {
+            const unsigned ri = (unsigned)wrun + ex[w];        // tile-local record index: 32 bits are plenty
+            if (n[w] > 0 && ri < a.stage_cap) stage[ri] = pos[w] | (m0[w] << 12);
+            if (n[w] == 2 && ri + 1 < a.stage_cap) stage[ri + 1] = pos[w] | (m1[w] << 12);
+            if (n[w] > 2)
+                walk_store<W8, false>(tile, s0, R, T, pos[w], lim, a.wbit, a.ht_size, a.num_final, stage, a.stage_cap, nullptr, 0, ri, 0);
+        }
+    }
+    return tot0 + tot1;
 }
 
 // Compaction + walk over one wave tile.  Survivors (set bits of the per-lane masks) are appended,
 // in position order, to a FIFO in LDS; whenever 64 are pending a full round runs, so lanes stay
 // busy even when only one offset in thirteen survives the root test.  Returns the tile's match
 // count; with DIRECT the records are written at global index wrun onwards.
-template <bool W8, bool DIRECT>
+template <bool W8, bool DIRECT, int NWALK>
 __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
                                                         const Dense1 &d1, const int *R, const int2 *T, unsigned short *q,
                                                         unsigned *stage, const unsigned (&masks)[SUBS], int lane,
                                                         unsigned lim, unsigned long long tile_base,
                                                         unsigned long long wrun) {
-    unsigned tail = 0;                         // pending survivors, always < 64 between sub-tiles
+    unsigned tail = 0;                         // pending survivors, always < one round between sub-tiles
     // per-lane survivor counts of the 4 sub-tiles, prefix-summed two at a time (16-bit fields: a
     // sub-tile holds at most 1024 survivors); the two independent DPP chains fill each other's wait states
     static_assert(SUBS == 4, "packed scans assume 4 sub-tiles");
@@ -466,20 +522,23 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
         for (unsigned m = mask; m; m &= m - 1) q[o++] = (unsigned short)(lpos + (__ffs(m) - 1));
         tail += S;
         wave_lds_sync();
+        constexpr unsigned RW = WAVE * NWALK;  // survivors per round
         unsigned h = 0;
-        for (; h + WAVE <= tail; h += WAVE)
-            wrun += round64<W8, DIRECT>(a, tile, s0, d1, R, T, q, h + lane, true, stage, lim, tile_base, wrun);
-        if (h) {                               // move the < 64 left-overs to the front
+        for (; h + RW <= tail; h += RW)
+            wrun += roundN<W8, DIRECT, NWALK>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
+        if (h) {                               // move the < RW left-overs to the front
             const unsigned rem = tail - h;
-            unsigned short v = 0;
-            if ((unsigned)lane < rem) v = q[h + lane];
+            unsigned short v[NWALK];
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) v[w] = (unsigned)lane + WAVE * w < rem ? q[h + WAVE * w + lane] : (unsigned short)0;
             wave_lds_sync();
-            if ((unsigned)lane < rem) q[lane] = v;
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) if ((unsigned)lane + WAVE * w < rem) q[WAVE * w + lane] = v[w];
             wave_lds_sync();
             tail = rem;
         }
     }
-    if (tail) wrun += round64<W8, DIRECT>(a, tile, s0, d1, R, T, q, lane, (unsigned)lane < tail, stage, lim, tile_base, wrun);
+    if (tail) wrun += roundN<W8, DIRECT, NWALK>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun);
     return wrun;
 }
 
@@ -758,7 +817,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * CAPW;
-        const unsigned long long cnt = tile_pass<W8, false>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
+        const unsigned long long cnt = tile_pass<W8, false, (TLDS ? 1 : 2)>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
         if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
         const bool overflow = cnt > a.stage_cap;
@@ -779,7 +838,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             // staging overflowed (or the automaton is too large for packed staging): emit this tile
             // now, while its bytes are still in LDS -- wait for the batch base, walk again to global
             unsigned long long base = 0;
-            if (record_base(r, base)) tile_pass<W8, true>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
+            if (record_base(r, base)) tile_pass<W8, true, (TLDS ? 1 : 2)>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
         }
         // ---- emit the tile of TWO rounds ago: its batch base has long been resolved
         if (have2) {
