@@ -50,7 +50,7 @@ constexpr int SUB = WAVE * 16;             // bytes one wave covers with one 16-
 constexpr int SUBS = 4;                    // such sub-tiles per wave tile
 constexpr int WTILE = SUB * SUBS;          // 4096: tile-local positions fit 12 bits
 constexpr int HALO_MAX = 1024;             // >= max_pat_len - 1 (patterns are < 1024 bytes), multiple of 16
-constexpr int QCAP = SUB + 2 * WAVE;       // survivor FIFO: < 128 carried over + up to 1024 appended
+constexpr int QCAP = SUB / 2 + 2 * WAVE;   // survivor FIFO: < 128 carried over + up to 512 appended at a time
 #ifndef PFAC_CAPW
 #define PFAC_CAPW 384
 #endif
@@ -518,24 +518,35 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
         const unsigned S = totals[j];
         if (S == 0) continue;
         const unsigned lpos = j * SUB + lane * 16;
-        unsigned o = tail + incl - cnt;
-        for (unsigned m = mask; m; m &= m - 1) q[o++] = (unsigned short)(lpos + (__ffs(m) - 1));
-        tail += S;
-        wave_lds_sync();
-        constexpr unsigned RW = WAVE * NWALK;  // survivors per round
-        unsigned h = 0;
-        for (; h + RW <= tail; h += RW)
-            wrun += roundN<W8, DIRECT, NWALK>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
-        if (h) {                               // move the < RW left-overs to the front
-            const unsigned rem = tail - h;
-            unsigned short v[NWALK];
-#pragma unroll
-            for (int w = 0; w < NWALK; w++) v[w] = (unsigned)lane + WAVE * w < rem ? q[h + WAVE * w + lane] : (unsigned short)0;
+        // A sub-tile with more than 512 survivors is appended in two lane halves (lanes 0-31 hold at most
+        // 32 * 16 = 512 of them, and come first in position order), so the FIFO needs 512 + 128 slots only.
+        const unsigned S_lo = __builtin_amdgcn_readlane(incl, 31);
+        const int nhalf = S > (unsigned)(SUB / 2) ? 2 : 1;
+        for (int hf = 0; hf < nhalf; hf++) {
+            const bool mine = nhalf == 1 || (lane >> 5) == hf;
+            const unsigned hbase = hf == 1 ? S_lo : 0u;
+            const unsigned hcnt = nhalf == 1 ? S : (hf == 0 ? S_lo : S - S_lo);
+            if (mine) {
+                unsigned o = tail + (incl - cnt) - hbase;
+                for (unsigned m = mask; m; m &= m - 1) q[o++] = (unsigned short)(lpos + (__ffs(m) - 1));
+            }
+            tail += hcnt;
             wave_lds_sync();
+            constexpr unsigned RW = WAVE * NWALK;  // survivors per round
+            unsigned h = 0;
+            for (; h + RW <= tail; h += RW)
+                wrun += roundN<W8, DIRECT, NWALK>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
+            if (h) {                               // move the < RW left-overs to the front
+                const unsigned rem = tail - h;
+                unsigned short v[NWALK];
 #pragma unroll
-            for (int w = 0; w < NWALK; w++) if ((unsigned)lane + WAVE * w < rem) q[WAVE * w + lane] = v[w];
-            wave_lds_sync();
-            tail = rem;
+                for (int w = 0; w < NWALK; w++) v[w] = (unsigned)lane + WAVE * w < rem ? q[h + WAVE * w + lane] : (unsigned short)0;
+                wave_lds_sync();
+#pragma unroll
+                for (int w = 0; w < NWALK; w++) if ((unsigned)lane + WAVE * w < rem) q[WAVE * w + lane] = v[w];
+                wave_lds_sync();
+                tail = rem;
+            }
         }
     }
     if (tail) wrun += roundN<W8, DIRECT, NWALK>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun);
