@@ -130,7 +130,8 @@ def main():
     def run_workload(name, steps, warmup):
         pat_name, kind, desc = WORKLOADS[name]
         ppath = pattern_path(pat_name, tmpdir)
-        g = GpuMatcher(local_rank, 1)
+        g = GpuMatcher(local_rank, 2)          # two buffer sets (slots) ...
+        g.set_stream(1, g.stream_handle(0))    # ... on ONE HIP stream: step k+1 is enqueued while step k runs
         if use_dist:
             table = PfacTable.from_file(ppath, 256) if rank == 0 else None
             blob, table = pdist.broadcast_table(table, dev, 0)             # RCCL broadcast of the table image
@@ -149,6 +150,8 @@ def main():
         cap = max(n_owned // 8, 1 << 20)
         g.reserve(0, 0, cap)
         n = g.scan_resident(n_owned, n_avail, d_input=buf)                 # sizes the record buffer, warms up
+        g.reserve(1, 0, max(cap, n))
+        assert g.scan_resident(n_owned, n_avail, d_input=buf, slot=1) == n
         # parity spot check (outside the timed region) on the FULL-SIZE launch itself: records are globally
         # ordered, so the matches that start in the first 4 MiB are a prefix of the record array -- compare that
         # prefix, record for record, with the CPU oracle run on the same bytes.
@@ -168,31 +171,45 @@ def main():
             raise SystemExit(f"rank {rank}: PARITY FAILURE on workload {name}: first {k} records differ from the oracle")
 
         pending = []
+        inflight = []                          # slots with an enqueued, not yet finished scan (depth <= 2)
+        kern_ms = []
 
-        def step():
-            g.scan_async(n_owned, n_avail, d_input=buf)
-            cnt, _ = g.scan_finish(0)
-            if use_dist:                       # record-placement exchange: overlaps the next scan
+        def finish_oldest():
+            sl = inflight.pop(0)
+            cnt, _ = g.scan_finish(sl)
+            kern_ms.append(g.elapsed_ms(sl))
+            if use_dist:                       # record-placement exchange: overlaps the following scans
                 pending.append(pdist.gather_counts_async(cnt, dev))
             return cnt
 
+        def step(k):
+            """One pass of the hot path over the resident shard.  The launch of step k overlaps the run of step
+            k-1 (same stream, alternate control/record buffers); every step's count is read back."""
+            sl = k & 1
+            g.scan_async(n_owned, n_avail, d_input=buf, slot=sl)
+            inflight.append(sl)
+            return finish_oldest() if len(inflight) == 2 else None
+
         def drain():
+            cnt = None
+            while inflight:
+                cnt = finish_oldest()
             for work, _ in pending:
                 work.wait()
             pending.clear()
+            return cnt
 
-        for _ in range(warmup):
-            step()
+        for k in range(warmup):
+            step(k)
         drain()
-        kern_ms = []
+        kern_ms.clear()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            cnt = step()
-            kern_ms.append(g.elapsed_ms(0))
-        drain()                                # every count exchange of the K steps has completed
+        for k in range(steps):
+            step(k)
+        cnt = drain()                          # all K scans finished, every count exchange completed
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -228,7 +245,7 @@ def main():
         "metric": "input GB/s scanned", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": res["desc"], "bytes_per_gpu": per, "global_bytes": n_total, "streams_per_gpu": 1,
+        "config": {"workload": res["desc"], "bytes_per_gpu": per, "global_bytes": n_total, "streams_per_gpu": 1, "launch_pipeline_depth": 2,
                    "phf_width": 256, "patterns": res["table"].n_patterns, "states": res["table"].state_num,
                    "kernel_variant": res["info"]["variant"], "tile_bytes": res["info"]["tile_bytes"],
                    "grid_blocks": res["info"]["grid_blocks"], "lds_bytes": res["info"]["lds_bytes"],

@@ -96,7 +96,9 @@ struct ScanArgs {
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
     unsigned stage_cap;                   // CAPW, or 0 when final states do not fit the packed staging word
     unsigned n_tiles;
-    unsigned *ctl;                 // [0] ticket, [1] error flags, [2..3] total matches (u64)
+    unsigned *ctl;                 // [0] batch ticket (device memory)
+    unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy:
+                                   // [0..1] total matches (u64), [2] error flags
     unsigned long long *status;    // one look-back word per batch
     unsigned long long *dbg;       // PFAC_TRACE only: per-round timestamps (10 ns units), else null
 };
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
     const int lane = tid & (WAVE - 1);
     const int wave = tid >> 6;
     const int nc = (int)(blockDim.x >> 6) - 1;             // compute waves; wave nc coordinates
-    unsigned *err = &a.ctl[1];
+    unsigned *err = &a.res[2];             // error paths only: an atomic on host memory is fine there
 
     // ---- once per workgroup: rings cleared, root row, root flag tables, (small) PHF tables -> LDS
     for (int i = tid; i < H_WORDS; i += blockDim.x) hdr[i] = 0;
@@ -705,8 +707,8 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
             if (lane == 0) {
                 lds_store(&hdr[H_READY + (p.r & 7)], p.r + 1);
                 if (p.end >= a.n_tiles) {                   // this batch holds the last tile: grand total
-                    a.ctl[2] = (unsigned)(excl + p.tot);
-                    a.ctl[3] = (unsigned)((excl + p.tot) >> 32);
+                    a.res[0] = (unsigned)(excl + p.tot);
+                    a.res[1] = (unsigned)((excl + p.tot) >> 32);
                 }
             }
         };
@@ -974,11 +976,12 @@ struct Slot {
     uint64_t record_cap = 0;
     unsigned *d_ctl = nullptr;            // 16 control words followed by the status array
     uint64_t status_cap = 0;              // tiles
-    unsigned *h_ctl = nullptr;            // pinned: [0] ticket [1] err [2..3] total, [4..5] checksum
+    unsigned *h_ctl = nullptr;            // pinned, device-visible: [0..1] total, [2] err (written by the kernel), [4..5] checksum
+    unsigned *d_res = nullptr;            // device-side address of h_ctl
     unsigned long long *d_sum = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t last_cap = 0;
-    bool scanned = false;
+    bool scanned = false, pending = false;
     unsigned long long *d_dbg = nullptr;  // PFAC_TRACE
 };
 
@@ -1159,8 +1162,9 @@ int pfac_ctx_create(int device, int n_streams, pfac_ctx **out) {
     for (auto &s : ctx->slots) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
         s.stream = s.own_stream;
-        HIP_TRY(ctx, hipHostMalloc((void **)&s.h_ctl, 64, hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc((void **)&s.h_ctl, 64, hipHostMallocMapped));
         memset(s.h_ctl, 0, 64);
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&s.d_res, s.h_ctl, 0));
         HIP_TRY(ctx, hipMalloc((void **)&s.d_sum, 16));
         HIP_TRY(ctx, hipEventCreate(&s.ev0));
         HIP_TRY(ctx, hipEventCreate(&s.ev1));
@@ -1277,12 +1281,18 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     if (!d_records && capacity) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: no record buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t n_tiles = (n_owned + WTILE - 1) / WTILE;
+    if (s.pending) HIP_TRY(ctx, hipStreamSynchronize(s.stream));   // the previous scan of this slot still owns h_ctl
     s.last_cap = capacity;
     s.scanned = true;
+    s.pending = true;
+    s.h_ctl[0] = s.h_ctl[1] = s.h_ctl[2] = 0;          // result words (the kernel writes them through the host mapping)
     rc = ensure_status(ctx, s, n_tiles);
     if (rc) return rc;
-    // control words + the status words this launch polls, zeroed every call
-    HIP_TRY(ctx, hipMemsetAsync(s.d_ctl, 0, 64 + align_up(n_tiles * 8, 16), s.stream));
+    // ticket + one look-back word per batch (+ the tickets taken ahead by every workgroup), zeroed every call
+    const uint64_t n_batches = (n_tiles + ctx->waves_per_block - 2) / (ctx->waves_per_block - 1);
+    uint64_t zero_words = n_batches + 4ull * ctx->grid_blocks + 8;
+    if (zero_words > s.status_cap) zero_words = s.status_cap;
+    HIP_TRY(ctx, hipMemsetAsync(s.d_ctl, 0, 64 + align_up(zero_words * 8, 16), s.stream));
     HIP_TRY(ctx, hipEventRecord(s.ev0, s.stream));
     if (n_tiles > 0) {
         ScanArgs a;
@@ -1298,6 +1308,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.root_byte = ctx->root_byte; a.stage_cap = ctx->stage_cap;
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = s.d_ctl;
+        a.res = s.d_res;
         a.status = reinterpret_cast<unsigned long long *>(s.d_ctl + 16);
         a.dbg = nullptr;
         if (getenv("PFAC_TRACE")) {
@@ -1311,7 +1322,6 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         HIP_TRY(ctx, hipLaunchKernel(ctx->kernel, dim3((unsigned)grid), dim3(WAVE * ctx->waves_per_block), kargs, (size_t)ctx->lds_bytes, s.stream));
     }
     HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_ctl, s.d_ctl, 16, hipMemcpyDeviceToHost, s.stream));
     return PFAC_OK;
 }
 
@@ -1322,7 +1332,8 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_scan_finish without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    const uint64_t total = ((uint64_t)s.h_ctl[3] << 32) | s.h_ctl[2];
+    s.pending = false;
+    const uint64_t total = ((uint64_t)s.h_ctl[1] << 32) | s.h_ctl[0];
     if (n_matches) *n_matches = total;
     if (s.d_dbg && getenv("PFAC_TRACE")) {
         std::vector<unsigned long long> h(8 * 64 * 32);
@@ -1330,7 +1341,7 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
             if (FILE *f = fopen(getenv("PFAC_TRACE"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         }
     }
-    if (s.h_ctl[1] != 0) return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a look-back timeout");
+    if (s.h_ctl[2] != 0) return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a look-back timeout");
     if (total > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "more matches than record capacity");
     return PFAC_OK;
 }

@@ -15,7 +15,7 @@ run)
   for i in 1 2 3; do
     for v in A B; do
       if [ $v = B ]; then export PFAC_HIP_LIB=$PWD/ab/libB.so; else unset PFAC_HIP_LIB; fi
-      python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $W 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$v', d['roofline']['achieved'], d['roofline']['kernel_ms_min'])"
+      python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $W 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$v', 'kernel', d['roofline']['achieved'], d['roofline']['kernel_ms_min'], 'value', d['value'], d['ms_per_step'])"
     done
   done;;
 esac
