@@ -75,7 +75,7 @@ constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
 constexpr unsigned long long ST_AGG = 1ull << 62;
 constexpr unsigned long long ST_INCL = 2ull << 62;
 constexpr unsigned long long ST_VAL = (1ull << 62) - 1;
-constexpr unsigned SPIN_MAX = 1u << 20;
+constexpr unsigned SPIN_MAX = 1u << 22;    // bounded spins: ~0.5 s of LDS polls, seconds of global polls
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

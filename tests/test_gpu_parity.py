@@ -319,3 +319,20 @@ def test_rccl_path_single_rank(resolve):
     assert got.size == pos.size
     np.testing.assert_array_equal(got["pos"].astype(np.int64), pos)
     np.testing.assert_array_equal(table.idmap[got["state"]], ids)
+
+
+def test_deeply_nested_patterns_every_offset_matches_hundreds(tmp_path):
+    """Worst case for the record path: patterns a, aa, ..., a^300 on an all-'a' input -> up to 300 matches per
+    start offset (the >2-matches re-walk, staging overflow + urgent look-back on every tile), millions of
+    records, still globally ordered by (position, length) and bit-exact."""
+    L = 300
+    pf = tmp_path / "nest"
+    order = np.random.default_rng(7).permutation(L) + 1
+    pf.write_bytes(b"".join(b"a" * int(k) + b"\n" for k in order))
+    table = PfacTable.from_file(str(pf), 256)
+    data = np.full(3 * TILE + 777, ord("a"), dtype=np.uint8)
+    data[TILE + 5] = ord("b")                                   # one break in the run
+    rec = gpu_records(table, data)
+    pos, ids = oracle_pairs(str(pf), data)
+    assert rec.size == pos.size and rec.size > 10_000_000
+    assert_same(table, rec, pos, ids)

@@ -4,10 +4,10 @@ set -e
 cd "$(dirname "$0")/.."
 D=tests/golden/data
 W=$(mktemp -d)
-python3 - "$W" <<'PY'
+python3 - "$W" "${SIZE:-1073741824}" <<'PY'
 import sys, os
 para = open("tests/golden/data/paragraph402","rb").read()
-n = 1 << 30
+n = int(sys.argv[2])
 with open(os.path.join(sys.argv[1], "text1g"), "wb") as f:
     blk = (para * (1 + (1 << 24) // 402))
     # keep the 402-byte phase continuous across blocks
@@ -19,8 +19,8 @@ with open(os.path.join(sys.argv[1], "text1g"), "wb") as f:
         off += k
     f.write(b"\n")
 PY
-for s in 1 4; do
-  for p in bytefile_10000byte experimentpattern; do
+for s in ${STREAMS:-1 4}; do
+  for p in ${PATS:-bytefile_10000byte experimentpattern}; do
     (
       cd $W
       T0=$(date +%s.%N)
