@@ -81,7 +81,11 @@ typedef struct pfac_table {
  * (patternsToPFAC :277) and the row-displacement perfect hash (phf.c:151),
  * in near-linear time and without the 4 GiB-per-chunk preallocation. */
 int pfac_table_build_file(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len);
-/* Same, from a memory image of a pattern file. */
+/* Escape-aware variant: the reference's read_pattern_ext()/fgetc_ext() (create_table_reorder.c:131-185,
+ * ctdef.h:37-99, dead code there): \a \b \t \n \v \f \r \' \" \\ \ooo \xNN inside patterns; only a real
+ * newline separates patterns, so patterns may contain newline bytes.  Everything downstream is unchanged. */
+int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len);
+/* Same as pfac_table_build_file, from a memory image of a pattern file. */
 int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len);
 void pfac_table_free(pfac_table *t);
 

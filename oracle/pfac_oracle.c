@@ -69,6 +69,42 @@ static void stable_sort(orc_pat *a, orc_pat *tmp, int n) {
  * running 1-based count; length must stay below 1024; the file must end in
  * '\n' (otherwise the reference accumulates EOF bytes until the 1024 check
  * trips and exits).  Returns 0 or a negative error. */
+/* fgetc_ext (ctdef.h:37-99): backslash escapes merged into one byte; a real newline becomes EOL (0x10A). */
+#define ORC_EOL 0x10A
+static int orc_fgetc_ext(FILE *fp) {
+    int ch0 = fgetc(fp), ch1;
+    int value = 0;
+    if (ch0 == '\\') {
+        ch1 = fgetc(fp);
+        if (feof(fp)) return ch0;
+        if (ch1 >= '0' && ch1 <= '9') {                     /* isdigit: "%3o" then fails on 8 and 9, value stays 0 */
+            ungetc(ch1, fp);
+            if (fscanf(fp, "%3o", (unsigned *)&value) != 1) value = 0;
+            return (int)((char)value);
+        }
+        switch (ch1) {
+            case 'a': return '\a';
+            case 'b': return '\b';
+            case 't': return '\t';
+            case 'n': return '\n';
+            case 'v': return '\v';
+            case 'f': return '\f';
+            case 'r': return '\r';
+            case '\'': case '\"': case '\\': return ch1;
+            case 'x':
+                if (fscanf(fp, "%2x", (unsigned *)&value) != 1) value = 0;
+                return (int)((char)value);
+            default:
+                ungetc(ch1, fp);
+                return ch0;
+        }
+    }
+    if (ch0 == '\n') return ORC_EOL;
+    return ch0;
+}
+
+static int orc_ext_mode = 0;   /* set by orc_build_ext around orc_read_patterns: read_pattern_ext (ctr.c:131-185) */
+
 static int orc_read_patterns(orc_model *m, const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) { snprintf(m->err, sizeof m->err, "cannot open pattern file %s", path); return -1; }
@@ -78,13 +114,13 @@ static int orc_read_patterns(orc_model *m, const char *path) {
     for (;;) {
         int len = 0, ch;
         for (;;) {
-            ch = fgetc(f);
+            ch = orc_ext_mode ? orc_fgetc_ext(f) : fgetc(f);
             str[len++] = (unsigned char)ch;
             if (len >= 1024) {
                 snprintf(m->err, sizeof m->err, "Pattern %d length over 1024.", n + 1);
                 fclose(f); free(p); return -2;
             }
-            if (ch == '\n') { len -= 1; n += 1; break; }
+            if (ch == (orc_ext_mode ? ORC_EOL : '\n')) { len -= 1; n += 1; break; }
         }
         if (n > cap) { cap *= 2; p = (orc_pat *)realloc(p, (size_t)cap * sizeof *p); }
         p[n - 1].id = n;
@@ -175,6 +211,14 @@ orc_model *orc_build(const char *pattern_file, int streamnum, int gpu_s) {
         if (m->max_len_arr[c] > m->max_len) m->max_len = m->max_len_arr[c];
         m->n_final[c] = cnt;
     }
+    return m;
+}
+
+/* same pipeline with read_pattern_ext() as the reader (dead code in the reference: nothing calls it) */
+orc_model *orc_build_ext(const char *pattern_file, int streamnum, int gpu_s) {
+    orc_ext_mode = 1;
+    orc_model *m = orc_build(pattern_file, streamnum, gpu_s);
+    orc_ext_mode = 0;
     return m;
 }
 

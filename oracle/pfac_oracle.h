@@ -50,6 +50,7 @@ typedef struct {
 
 
 orc_model *orc_build(const char *pattern_file, int streamnum, int gpu_s);
+orc_model *orc_build_ext(const char *pattern_file, int streamnum, int gpu_s);
 const char *orc_error(const orc_model *m);
 int orc_ffdm(orc_model *m, int width, int exact);
 int orc_phf_lookup(const orc_model *m, int c, int state, int ch);

@@ -98,6 +98,30 @@ orc_model *ref_build_single(const char *pattern_file) {
     return m;
 }
 
+/* The reference's escape-aware reader read_pattern_ext (ctr.c:131-185, fgetc_ext ctdef.h:37-99) -- dead code
+ * there, called here directly -- then its trie builder over ONE chunk. */
+orc_model *ref_build_single_ext(const char *pattern_file) {
+    Quiet q;
+    INITIAL_PFAC_SIZE = 1 << 16;
+    INITIAL_SIZE = 100000;
+    GPU_N = 1;
+    int pattern_num = 0;
+    pattern_s *all = (pattern_s *)malloc(INITIAL_SIZE * sizeof(pattern_s));
+    read_pattern_ext((char *)pattern_file, &pattern_num, all);
+    int *state_num = (int *)calloc(1, sizeof(int));
+    int *final_num = (int *)calloc(1, sizeof(int));
+    int *max_len_arr = (int *)calloc(1, sizeof(int));
+    int ***PFACs = (int ***)malloc(sizeof(int **));
+    int **idmaps = (int **)malloc(sizeof(int *));
+    PFACs[0] = (int **)malloc(INITIAL_PFAC_SIZE * sizeof(int *));
+    idmaps[0] = (int *)malloc((pattern_num + 1) * sizeof(int));
+    PFACs[0] = patternsToPFAC(all + 1, pattern_num, PFACs[0], &max_len_arr[0], &state_num[0], idmaps[0]);
+    final_num[0] = pattern_num;
+    orc_model *m = wrap(1, state_num, final_num, max_len_arr, max_len_arr[0], PFACs, idmaps);
+    m->n_pat = pattern_num;
+    return m;
+}
+
 /* FFDM (phf.c:151) per chunk, as main.cc:123-126 calls it (serially here). */
 int ref_ffdm(orc_model *m, int width) {
     Quiet q;

@@ -65,7 +65,7 @@ class CThreadData(C.Structure):
 
 
 HOST_SYMBOLS = (
-    "pfac_table_build_file", "pfac_table_build_mem", "pfac_table_free", "pfac_table_lookup",
+    "pfac_table_build_file", "pfac_table_build_file_escaped", "pfac_table_build_mem", "pfac_table_free", "pfac_table_lookup",
     "pfac_table_blob_words", "pfac_table_to_blob", "pfac_table_from_blob", "pfac_table_from_reference_arrays",
     "pfac_emit_records", "pfac_emit_records_mt",
 )
@@ -92,6 +92,7 @@ def host_lib() -> C.CDLL:
         L = C.CDLL(path)
         TP = C.POINTER(CTable)
         L.pfac_table_build_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(TP), C.c_char_p, C.c_size_t]
+        L.pfac_table_build_file_escaped.argtypes = [C.c_char_p, C.c_int, C.POINTER(TP), C.c_char_p, C.c_size_t]
         L.pfac_table_build_mem.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(TP), C.c_char_p, C.c_size_t]
         L.pfac_table_free.argtypes = [TP]
         L.pfac_table_free.restype = None

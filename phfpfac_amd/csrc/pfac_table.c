@@ -36,7 +36,8 @@
 #include <string.h>
 #include <unistd.h>
 
-#define PFAC_MAX_PATTERN_LEN 1023   /* str[1024] with the '\n' (create_table_reorder.c:55,74) */
+#define PFAC_MAX_PATTERN_LEN 1022   /* the reader stores the '\n' too and rejects str_len >= 1024 BEFORE looking at
+                                       it (create_table_reorder.c:72-83): 1022 bytes is the longest pattern it accepts */
 #define PFAC_COL_MAX 4096           /* phf.c:8 */
 
 typedef struct {
@@ -193,6 +194,10 @@ static int build_phf(pfac_table *t, const edge_t *edges, int32_t n_edges, char *
     return PFAC_OK;
 }
 
+/* sort + trie + PHF over n patterns (ids and bytes filled in by a reader; pats is consumed) */
+static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_t max_len, int width, pfac_table **out,
+                               char *err, size_t err_len);
+
 int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len) {
     if (!patterns || !out) { set_err(err, err_len, "null argument%ld", 0); return PFAC_E_ARG; }
     *out = NULL;
@@ -208,15 +213,14 @@ int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_t
     for (size_t i = 0; i < n_bytes; i++) n_lines += (buf[i] == '\n');
     if (n_lines > (size_t)INT32_MAX / 2) { set_err(err, err_len, "too many patterns (%ld)", (long)n_lines); return PFAC_E_PATTERN; }
     pat_t *pats = (pat_t *)malloc(n_lines * sizeof(pat_t));
-    pat_t *tmp = (pat_t *)malloc(n_lines * sizeof(pat_t));
-    if (!pats || !tmp) { free(pats); free(tmp); set_err(err, err_len, "out of memory (%ld patterns)", (long)n_lines); return PFAC_E_NOMEM; }
+    if (!pats) { set_err(err, err_len, "out of memory (%ld patterns)", (long)n_lines); return PFAC_E_NOMEM; }
     size_t start = 0, n = 0;
     int32_t max_len = 0;
     for (size_t i = 0; i < n_bytes; i++) {
         if (buf[i] != '\n') continue;
         size_t len = i - start;
-        if (len == 0) { free(pats); free(tmp); set_err(err, err_len, "pattern %ld is empty", (long)n + 1); return PFAC_E_PATTERN; }
-        if (len > PFAC_MAX_PATTERN_LEN) { free(pats); free(tmp); set_err(err, err_len, "Pattern %ld length over 1024.", (long)n + 1); return PFAC_E_PATTERN; }
+        if (len == 0) { free(pats); set_err(err, err_len, "pattern %ld is empty", (long)n + 1); return PFAC_E_PATTERN; }
+        if (len > PFAC_MAX_PATTERN_LEN) { free(pats); set_err(err, err_len, "Pattern %ld length over 1024.", (long)n + 1); return PFAC_E_PATTERN; }
         pats[n].id = (int32_t)(n + 1);
         pats[n].len = (int32_t)len;
         pats[n].pat = buf + start;
@@ -224,11 +228,119 @@ int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_t
         n++;
         start = i + 1;
     }
+    return build_from_patterns(pats, n, n_bytes - n_lines, max_len, width, out, err, err_len);
+}
+
+/*
+ * Escape-aware reader: the reference's read_pattern_ext() / fgetc_ext() (create_table_reorder.c:131-185,
+ * ctdef.h:37-99; present but never called there).  Inside a pattern a backslash introduces
+ *   \a \b \t \n \v \f \r   control characters      \' \" \\   the character itself
+ *   \ooo   up to three octal digits (fscanf "%3o")     \xNN   up to two hex digits (fscanf "%2x")
+ * any other "\c" is a literal backslash followed by c; only a REAL newline ends a pattern, so patterns may
+ * contain '\n' bytes.  The same libc scanning calls are used on the stream, so odd inputs ("\8", "\x" with no
+ * digits -> byte 0) resolve exactly as they would there.
+ */
+#define PFAC_EOL 0x10A
+static int fgetc_escaped(FILE *fp) {
+    int c0 = fgetc(fp);
+    if (c0 == '\\') {
+        int c1 = fgetc(fp);
+        unsigned value = 0;
+        if (feof(fp)) return c0;
+        if (c1 >= '0' && c1 <= '9') {
+            ungetc(c1, fp);
+            if (fscanf(fp, "%3o", &value) != 1) value = 0;
+            return (int)(char)value;
+        }
+        switch (c1) {
+            case 'a': return '\a';
+            case 'b': return '\b';
+            case 't': return '\t';
+            case 'n': return '\n';
+            case 'v': return '\v';
+            case 'f': return '\f';
+            case 'r': return '\r';
+            case '\'': case '"': case '\\': return c1;
+            case 'x':
+                if (fscanf(fp, "%2x", &value) != 1) value = 0;
+                return (int)(char)value;
+            default:
+                ungetc(c1, fp);
+                return c0;
+        }
+    }
+    if (c0 == '\n') return PFAC_EOL;
+    return c0;
+}
+
+int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len) {
+    if (!pattern_file || !out) return PFAC_E_ARG;
+    *out = NULL;
+    if (!is_pow2(width) || width > PFAC_COL_MAX) {
+        set_err(err, err_len, "PHF width %ld must be a power of two <= 4096", width); return PFAC_E_ARG;
+    }
+    FILE *f = fopen(pattern_file, "rb");
+    if (!f) { if (err && err_len) snprintf(err, err_len, "cannot open pattern file %s", pattern_file); return PFAC_E_IO; }
+    size_t cap = 1024, n = 0, arena_cap = 1 << 16, arena_len = 0, total = 0;
+    pat_t *pats = (pat_t *)malloc(cap * sizeof(pat_t));
+    size_t *offs = (size_t *)malloc(cap * sizeof(size_t));
+    unsigned char *arena = (unsigned char *)malloc(arena_cap);
+    int32_t max_len = 0;
+    int rc = PFAC_OK;
+    unsigned char str[PFAC_MAX_PATTERN_LEN + 2];
+    while (pats && offs && arena) {
+        int len = 0, ch, eof_inside = 0;
+        for (;;) {
+            ch = fgetc_escaped(f);
+            if (ch == PFAC_EOL) break;
+            if (ch == EOF && feof(f)) { eof_inside = 1; break; }
+            str[len++] = (unsigned char)ch;
+            if (len > PFAC_MAX_PATTERN_LEN) break;
+        }
+        if (eof_inside) { set_err(err, err_len, "pattern file must end with a newline (pattern %ld)", (long)n + 1); rc = PFAC_E_PATTERN; break; }
+        if (len > PFAC_MAX_PATTERN_LEN) { set_err(err, err_len, "Pattern %ld length over 1024.", (long)n + 1); rc = PFAC_E_PATTERN; break; }
+        if (len == 0) { set_err(err, err_len, "pattern %ld is empty", (long)n + 1); rc = PFAC_E_PATTERN; break; }
+        if (n == cap) {
+            cap *= 2;
+            pats = (pat_t *)realloc(pats, cap * sizeof(pat_t));
+            offs = (size_t *)realloc(offs, cap * sizeof(size_t));
+            if (!pats || !offs) break;
+        }
+        if (arena_len + (size_t)len > arena_cap) {
+            arena_cap *= 2;
+            arena = (unsigned char *)realloc(arena, arena_cap);
+            if (!arena) break;
+        }
+        memcpy(arena + arena_len, str, (size_t)len);
+        offs[n] = arena_len;
+        pats[n].id = (int32_t)(n + 1);
+        pats[n].len = len;
+        arena_len += (size_t)len;
+        total += (size_t)len;
+        if (len > max_len) max_len = len;
+        n++;
+        ch = fgetc(f);                                  /* end of file after a newline? (ctr.c:174-180) */
+        if (feof(f)) break;
+        ungetc(ch, f);
+    }
+    fclose(f);
+    if (!pats || !offs || !arena) { free(pats); free(offs); free(arena); set_err(err, err_len, "out of memory (%ld patterns)", (long)n); return PFAC_E_NOMEM; }
+    if (rc) { free(pats); free(offs); free(arena); return rc; }
+    for (size_t i = 0; i < n; i++) pats[i].pat = arena + offs[i];
+    free(offs);
+    rc = build_from_patterns(pats, n, total, max_len, width, out, err, err_len);
+    free(arena);
+    return rc;
+}
+
+static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_t max_len, int width, pfac_table **out,
+                               char *err, size_t err_len) {
+    pat_t *tmp = (pat_t *)malloc((n ? n : 1) * sizeof(pat_t));
+    if (!tmp) { free(pats); set_err(err, err_len, "out of memory (%ld patterns)", (long)n); return PFAC_E_NOMEM; }
     merge_sort(pats, tmp, n);
     free(tmp);
 
     /* ---- trie as an edge list (LCP stack over the sorted list) ---- */
-    size_t total_bytes = n_bytes - n_lines;
     if ((int64_t)n + 2 + (int64_t)total_bytes > INT32_MAX / 256) {
         /* keys are (state<<8)+ch in int32 on the device (master_kernel.cu:52) */
         free(pats); set_err(err, err_len, "automaton too large (%ld pattern bytes)", (long)total_bytes); return PFAC_E_PATTERN;

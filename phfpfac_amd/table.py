@@ -39,11 +39,13 @@ class PfacTable:
 
     # -- construction -----------------------------------------------------
     @classmethod
-    def from_file(cls, pattern_file: str, width: int = 256) -> "PfacTable":
+    def from_file(cls, pattern_file: str, width: int = 256, escapes: bool = False) -> "PfacTable":
+        """``escapes=True`` reads the file like the reference's ``read_pattern_ext`` (backslash escapes)."""
         L = host_lib()
         ptr = C.POINTER(CTable)()
         err = C.create_string_buffer(256)
-        rc = L.pfac_table_build_file(os.fsencode(pattern_file), int(width), C.byref(ptr), err, 256)
+        fn = L.pfac_table_build_file_escaped if escapes else L.pfac_table_build_file
+        rc = fn(os.fsencode(pattern_file), int(width), C.byref(ptr), err, 256)
         if rc:
             raise PfacError(rc, err.value.decode(errors="replace"))
         return cls(ptr)

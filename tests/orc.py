@@ -14,6 +14,7 @@ def lib():
         L = C.CDLL(os.path.join(REPO, "oracle", "liboracle.so"))
         vp, i = C.c_void_p, C.c_int
         L.orc_build.restype = vp; L.orc_build.argtypes = [C.c_char_p, i, i]
+        L.orc_build_ext.restype = vp; L.orc_build_ext.argtypes = [C.c_char_p, i, i]
         L.orc_error.restype = C.c_char_p; L.orc_error.argtypes = [vp]
         L.orc_free.argtypes = [vp]; L.orc_free.restype = None
         L.orc_ffdm.argtypes = [vp, i, i]
@@ -49,9 +50,10 @@ def lib():
 class Oracle:
     """CPU restatement of the reference pipeline for one pattern file."""
 
-    def __init__(self, pattern_file, streamnum=1, gpu_s=4):
+    def __init__(self, pattern_file, streamnum=1, gpu_s=4, escapes=False):
         self.L = lib()
-        self.m = self.L.orc_build(os.fsencode(pattern_file), streamnum, gpu_s)
+        build = self.L.orc_build_ext if escapes else self.L.orc_build
+        self.m = build(os.fsencode(pattern_file), streamnum, gpu_s)
         e = self.L.orc_error(self.m)
         if e:
             raise RuntimeError(e.decode())

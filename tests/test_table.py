@@ -102,9 +102,9 @@ def test_reader_errors_are_reported_not_fatal(tmp_path):
         build(b"abc\n\nde\n")                      # empty line
     assert e.value.status == -3
     with pytest.raises(PfacError) as e:
-        build(b"a" * 1024 + b"\n")                 # "Pattern 1 length over 1024."
-    assert e.value.status == -3 and "length over 1024" in str(e.value)
-    assert build(b"a" * 1023 + b"\n").max_pat_len == 1023
+        build(b"a" * 1023 + b"\n")                 # "Pattern 1 length over 1024.": the reference's reader counts the
+    assert e.value.status == -3 and "length over 1024" in str(e.value)      # newline too (ctr.c:72-83) -> 1022 max
+    assert build(b"a" * 1022 + b"\n").max_pat_len == 1022
     for w in (0, 3, 8192, -4):
         with pytest.raises(PfacError) as e:
             build(b"a\n", w)
@@ -144,3 +144,52 @@ def test_parallel_emitter_is_byte_identical(tmp_path):
         nb = emit_records(str(b), rec, idmap, base=base, append=base != 0, threads=5)
         assert na == nb
     assert a.read_bytes() == b.read_bytes()
+
+
+ESCAPED = (b"tab\\there\n"            # \t
+           b"nl\\nin\\\\side\n"   # \n and \\ inside one pattern
+           b"hex\\x41\\xfe\\x7\n"  # \x41 \xfe \x7
+           b"oct\\101\\7\\377\\0end\n"   # \101 \7 \377 \0
+           b"odd\\8\\q\\'\\\"\n"        # \8 (no octal digit -> byte 0, then '8'), \q (literal backslash), \' \"
+           b"plain\n")
+
+
+def test_escape_aware_reader(tmp_path):
+    """pfac_table_build_file_escaped == the reference's read_pattern_ext/fgetc_ext (dead code there, restated in the
+    oracle and -- when oracle/_ref is built -- called for real): same tries, same ids, newline bytes inside patterns."""
+    import ctypes as C
+    import os
+    pf = tmp_path / "esc"
+    pf.write_bytes(ESCAPED)
+    t = PfacTable.from_file(str(pf), 256, escapes=True)
+    o = Oracle(str(pf), 1, 1, escapes=True)
+    dense = o.trie()
+    assert t.n_patterns == 6 and t.state_num == dense.shape[0]
+    assert (lookup_all(t) == dense).all() and (t.idmap == o.idmap()).all()
+    # spot-check the unescaped bytes through the automaton: walk "nl\nin\\side" from the root
+    s = t.num_final + 1
+    for ch in b"nl\nin\\side":
+        s = t.lookup(s, ch)
+        assert s >= 0
+    assert s < t.num_final and t.idmap[s] == 2
+    for pat, pid in ((b"hexA\xfe\x07", 3), (b"octA\x07\xff\x00end", 4), (b"odd\x008\\q'\"", 5), (b"tab\there", 1)):
+        s = t.num_final + 1
+        for ch in pat:
+            s = t.lookup(s, ch)
+            assert s >= 0, (pat, ch)
+        assert t.idmap[s] == pid
+    # the plain reader sees the same file as 6 different (longer) patterns
+    assert PfacTable.from_file(str(pf), 256).max_pat_len > t.max_pat_len
+    ref_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libpfacref.so")
+    if os.path.exists(ref_lib):
+        ref = C.CDLL(ref_lib)
+        ref.ref_build_single_ext.restype = C.c_void_p; ref.ref_build_single_ext.argtypes = [C.c_char_p]
+        ref.orc_state_num.argtypes = [C.c_void_p, C.c_int]
+        ref.orc_trie_row.restype = C.POINTER(C.c_int); ref.orc_trie_row.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        ref.orc_idmap.restype = C.POINTER(C.c_int); ref.orc_idmap.argtypes = [C.c_void_p, C.c_int]
+        b = ref.ref_build_single_ext(os.fsencode(str(pf)))
+        assert ref.orc_state_num(b, 0) == dense.shape[0]
+        for st in range(dense.shape[0]):
+            assert (np.ctypeslib.as_array(ref.orc_trie_row(b, 0, st), (256,)) == dense[st]).all()
+        assert (np.ctypeslib.as_array(ref.orc_idmap(b, 0), (6,)) == o.idmap()).all()
+    o.close()
