@@ -70,6 +70,18 @@ def test_gphf_cli_config1(resolve, tmp_path):
     assert hashlib.md5(blob).hexdigest() == FP["cases"]["exp_x_1M_s1_w256"]["md5"]
     r = subprocess.run([exe, "a", "b"], cwd=tmp_path, capture_output=True)
     assert r.returncode != 0 and b"usage:" in r.stderr        # argc check, main.cc:93-96
+    # streaming ingest + in-order emitter over many chunks: 6 MiB of text, 1 MiB chunks, 3 pipeline slots,
+    # dictionary patterns (matches straddle chunk boundaries); expected file from the CPU oracle
+    para = open(resolve("paragraph402"), "rb").read()
+    big = tmp_path / "big.txt"
+    n = 6 * (1 << 20) + 12345
+    big.write_bytes(tiled_bytes(n + 1, para).tobytes())        # + the byte the CLI drops (main.cc:138)
+    subprocess.check_call([exe, resolve("xaa"), "3", "1024", str(big)], cwd=tmp_path, env=env, stdout=subprocess.DEVNULL)
+    o = Oracle(resolve("xaa"), 1, 1)
+    exp = tmp_path / "expected.txt"
+    o.emit(tiled_bytes(n, para), str(exp), spec=True)
+    o.close()
+    assert (tmp_path / "GPU_match_result.txt").read_bytes() == exp.read_bytes()
 
 
 @pytest.mark.parametrize("width", [256, 64, 1024, 4096])
