@@ -71,6 +71,10 @@ constexpr int D1_MAX = 32;                 // at most this many depth-1 states g
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
 constexpr int NBUF = 3;                    // staging buffers: a tile's records are emitted two rounds later
 constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
+// Dense mode (most tiles hold more matches than CAPW, e.g. a dictionary on text): ONE big staging buffer per
+// wave and synchronous emission -- fewer waves fit, but a tile is walked once instead of twice.
+constexpr int CAPW_DENSE = 3072;
+constexpr int PW_FIXED_DENSE = WTILE + QCAP * 2 + CAPW_DENSE * 4;
 
 constexpr unsigned long long ST_AGG = 1ull << 62;
 constexpr unsigned long long ST_INCL = 2ull << 62;
@@ -94,11 +98,13 @@ struct ScanArgs {
     const unsigned char *d1idx;           // root byte -> dense row index
     int d1_rows;                          // 0: no dense level
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
-    unsigned stage_cap;                   // CAPW, or 0 when final states do not fit the packed staging word
+    unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
+    unsigned nbuf;                        // staging buffers per wave: 3 = emit two rounds late, 1 = emit at once (dense mode)
+    unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
     unsigned n_tiles;
     unsigned *ctl;                 // [0] batch ticket (device memory)
     unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy:
-                                   // [0..1] total matches (u64), [2] error flags
+                                   // [0..1] total matches (u64), [2] error flags, [3] tiles denser than sparse_cap
     unsigned long long *status;    // one look-back word per batch
     unsigned long long *dbg;       // PFAC_TRACE only: per-round timestamps (10 ns units), else null
 };
@@ -153,7 +159,8 @@ constexpr int H_READY = 24;                // == r + 1 once H_GBASE is valid
 constexpr int H_URGENT = 32;               // != 0: a wave of round r needs its base right away (staging overflow)
 constexpr int H_CNT = 48;                  // 16 words per round: match count of each compute wave
 constexpr int H_WBASE = H_CNT + RING * 16; // 32 words per round: {lo, hi} first record index of each compute wave
-constexpr int H_WORDS = H_WBASE + RING * 32;
+constexpr int H_OVF = H_WBASE + RING * 32;  // tiles of this workgroup with more matches than sparse_cap
+constexpr int H_WORDS = H_OVF + 8;
 
 __device__ __forceinline__ unsigned lds_load(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -745,6 +752,9 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         }
         if (p2.on) resolve(p2, &win);
         if (p1.on) resolve(p1, nullptr);
+        // every count of this workgroup has been posted by now: report how many tiles were denser than the sparse
+        // staging capacity (the host switches staging mode on it)
+        if (lane == 0) { const unsigned ovf = lds_load(&hdr[H_OVF]); if (ovf) atomicAdd(&a.res[3], ovf); }
         return;
     }
 
@@ -829,15 +839,17 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
 
         if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
-        unsigned *stage = stage0 + buf * CAPW;
+        unsigned *stage = stage0 + buf * a.stage_cap;
         const unsigned long long cnt = tile_pass<W8, false, (TLDS ? 1 : 2)>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
         if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
         const bool overflow = cnt > a.stage_cap;
+        const bool now = overflow || a.nbuf == 1;          // this tile is emitted right away (needs its base at once)
         unsigned arrival = 0;
         if (lane == 0) {
             hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
-            if (overflow) lds_store(&hdr[H_URGENT + (r & 7)], 1u);
+            if (now) lds_store(&hdr[H_URGENT + (r & 7)], 1u);
+            if (cnt > a.sparse_cap) atomicAdd(&hdr[H_OVF], 1u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             arrival = atomicAdd(&hdr[H_ARRIVED + (r & 7)], 1u);
         }
@@ -847,23 +859,28 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         if (__builtin_amdgcn_readfirstlane(arrival) * 2u >= (unsigned)nc) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
 
-        if (overflow) {
-            // staging overflowed (or the automaton is too large for packed staging): emit this tile
-            // now, while its bytes are still in LDS -- wait for the batch base, walk again to global
+        if (now) {
             unsigned long long base = 0;
-            if (record_base(r, base)) tile_pass<W8, true, (TLDS ? 1 : 2)>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
+            if (record_base(r, base)) {
+                if (overflow)
+                    // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
+                    // while its bytes are still in LDS, writing straight to global memory
+                    tile_pass<W8, true, (TLDS ? 1 : 2)>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
+                else
+                    copy_out(a, stage, (unsigned)cnt, base, tile_base, lane);   // dense mode: staged, emitted at once
+            }
         }
         // ---- emit the tile of TWO rounds ago: its batch base has long been resolved
         if (have2) {
             unsigned long long base = 0;
             const bool okb = record_base(r - 2, base);
             if (trace) tr[9] = __builtin_amdgcn_s_memrealtime();
-            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
+            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, t2 * WTILE, lane);
         }
         if (trace) tr[8] = __builtin_amdgcn_s_memrealtime();
         have2 = have1; cnt2 = cnt1; t2 = t1;
-        have1 = !overflow; cnt1 = (unsigned)cnt; t1 = t;
-        buf = (buf + 1) % NBUF;
+        have1 = !now; cnt1 = (unsigned)cnt; t1 = t;
+        buf = a.nbuf == 1 ? 0u : (buf + 1) % NBUF;
         if (!more) break;
         t = t_next;
         r++;
@@ -871,11 +888,11 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
     // drain: the last two rounds' tiles (staged in buffers buf+1 [two rounds ago] and buf+2 [last round])
     if (have2) {
         unsigned long long base = 0;
-        if (record_base(r - 1, base)) copy_out(a, stage0 + ((buf + 1) % NBUF) * CAPW, cnt2, base, t2 * WTILE, lane);
+        if (record_base(r - 1, base)) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, t2 * WTILE, lane);
     }
     if (have1) {
         unsigned long long base = 0;
-        if (record_base(r, base)) copy_out(a, stage0 + ((buf + 2) % NBUF) * CAPW, cnt1, base, t1 * WTILE, lane);
+        if (record_base(r, base)) copy_out(a, stage0 + ((buf + 2) % NBUF) * a.stage_cap, cnt1, base, t1 * WTILE, lane);
     }
 }
 
@@ -980,8 +997,8 @@ struct Slot {
     unsigned *d_res = nullptr;            // device-side address of h_ctl
     unsigned long long *d_sum = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    uint64_t last_cap = 0;
-    bool scanned = false, pending = false;
+    uint64_t last_cap = 0, last_tiles = 0;
+    bool scanned = false, pending = false, last_dense = false;
     unsigned long long *d_dbg = nullptr;  // PFAC_TRACE
 };
 
@@ -1002,6 +1019,11 @@ struct pfac_ctx {
     const void *kernel = nullptr;
     int lds_bytes = 0, shared_bytes = 0, pw_bytes = 0, halo = 0, waves_per_block = 0, root_mode = 0;
     unsigned root_byte = 0, stage_cap = 0;
+    // the dense-mode twin of {pw_bytes, waves_per_block, lds_bytes, stage_cap}: one big staging buffer per wave
+    int pw_bytes_d = 0, waves_per_block_d = 0, lds_bytes_d = 0;
+    unsigned stage_cap_d = 0;
+    bool dense = false;                   // current staging mode (adapts to the match density seen by the last scan)
+    int dense_forced = -1;                // PFAC_DENSE=0/1 pins the mode
     int *d_d1 = nullptr;                  // dense depth-1 rows + (after them) the 256-byte row index
     int d1_rows = 0;
     int grid_blocks = 0;
@@ -1085,6 +1107,16 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->root_mode = fan == 1 ? 1 : 0;
     ctx->root_byte = (unsigned)rb * 0x01010101u;
     ctx->stage_cap = ctx->num_final <= (1 << PACK_STATE_BITS) ? (unsigned)CAPW : 0u;
+    // dense-mode layout
+    ctx->pw_bytes_d = (int)align_up((size_t)PW_FIXED_DENSE + ctx->halo, 16);
+    int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
+    if (nwd > MAX_WAVES_PER_BLOCK) nwd = MAX_WAVES_PER_BLOCK;
+    ctx->waves_per_block_d = nwd;
+    ctx->lds_bytes_d = ctx->shared_bytes + (nwd - 1) * ctx->pw_bytes_d;
+    if (ctx->lds_bytes_d < LDS_TOTAL / 2 + 256) ctx->lds_bytes_d = LDS_TOTAL / 2 + 256;
+    ctx->stage_cap_d = (nwd >= 4 && ctx->stage_cap) ? (unsigned)CAPW_DENSE : 0u;   // 0: dense mode unavailable
+    ctx->dense_forced = getenv("PFAC_DENSE") ? atoi(getenv("PFAC_DENSE")) : -1;
+    ctx->dense = ctx->dense_forced == 1 && ctx->stage_cap_d;
     const bool w8 = ctx->width_bit == 8;
     const void *k[2][2][2] = {
         {{(const void *)pfac_scan_kernel<false, false, 0>, (const void *)pfac_scan_kernel<false, false, 1>},
@@ -1092,7 +1124,8 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         {{(const void *)pfac_scan_kernel<true, false, 0>, (const void *)pfac_scan_kernel<true, false, 1>},
          {(const void *)pfac_scan_kernel<true, true, 0>, (const void *)pfac_scan_kernel<true, true, 1>}}};
     ctx->kernel = k[ctx->variant == 0 ? 1 : 0][w8 ? 1 : 0][ctx->root_mode];
-    HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     ctx->lds_bytes > ctx->lds_bytes_d ? ctx->lds_bytes : ctx->lds_bytes_d));
     return PFAC_OK;
 }
 
@@ -1288,8 +1321,15 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     s.h_ctl[0] = s.h_ctl[1] = s.h_ctl[2] = 0;          // result words (the kernel writes them through the host mapping)
     rc = ensure_status(ctx, s, n_tiles);
     if (rc) return rc;
+    // staging mode of this launch (see pfac_scan_finish for the adaptation)
+    const bool dense = ctx->dense && ctx->stage_cap_d;
+    const int wpb = dense ? ctx->waves_per_block_d : ctx->waves_per_block;
+    const int lds_bytes = dense ? ctx->lds_bytes_d : ctx->lds_bytes;
+    s.last_dense = dense;
+    s.last_tiles = n_tiles;
+    s.h_ctl[3] = 0;
     // ticket + one look-back word per batch (+ the tickets taken ahead by every workgroup), zeroed every call
-    const uint64_t n_batches = (n_tiles + ctx->waves_per_block - 2) / (ctx->waves_per_block - 1);
+    const uint64_t n_batches = (n_tiles + wpb - 2) / (wpb - 1);
     uint64_t zero_words = n_batches + 4ull * ctx->grid_blocks + 8;
     if (zero_words > s.status_cap) zero_words = s.status_cap;
     HIP_TRY(ctx, hipMemsetAsync(s.d_ctl, 0, 64 + align_up(zero_words * 8, 16), s.stream));
@@ -1302,10 +1342,13 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.r_words = ctx->max_row; a.t_entries = ctx->ht_size;
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
         a.halo = ctx->halo;
-        a.shared_bytes = ctx->shared_bytes; a.pw_bytes = ctx->pw_bytes;
+        a.shared_bytes = ctx->shared_bytes; a.pw_bytes = dense ? ctx->pw_bytes_d : ctx->pw_bytes;
         a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows;
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
-        a.root_byte = ctx->root_byte; a.stage_cap = ctx->stage_cap;
+        a.root_byte = ctx->root_byte;
+        a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
+        a.nbuf = dense ? 1u : (unsigned)NBUF;
+        a.sparse_cap = ctx->stage_cap;
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = s.d_ctl;
         a.res = s.d_res;
@@ -1316,10 +1359,10 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
             HIP_TRY(ctx, hipMemsetAsync(s.d_dbg, 0, 8 * 64 * 32 * 8, s.stream));
             a.dbg = s.d_dbg;
         }
-        const uint64_t want = (n_tiles + ctx->waves_per_block - 2) / (ctx->waves_per_block - 1);   // batches
+        const uint64_t want = n_batches;
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
         void *kargs[] = {&a};
-        HIP_TRY(ctx, hipLaunchKernel(ctx->kernel, dim3((unsigned)grid), dim3(WAVE * ctx->waves_per_block), kargs, (size_t)ctx->lds_bytes, s.stream));
+        HIP_TRY(ctx, hipLaunchKernel(ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
     }
     HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
     return PFAC_OK;
@@ -1342,6 +1385,14 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
         }
     }
     if (s.h_ctl[2] != 0) return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a look-back timeout");
+    // Staging mode for the NEXT scans of this context: when more than a quarter of the tiles held more matches
+    // than the small (three-buffer) staging area takes, go dense (one big buffer, emitted at once, no second
+    // walk); go back when fewer than 1/16 do.  PFAC_DENSE=0/1 pins the mode.
+    if (ctx->dense_forced < 0 && ctx->stage_cap_d && s.last_tiles >= 64) {
+        const uint64_t ovf = s.h_ctl[3];
+        if (!ctx->dense && ovf * 4 > s.last_tiles) ctx->dense = true;
+        else if (ctx->dense && ovf * 16 < s.last_tiles) ctx->dense = false;
+    }
     if (total > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "more matches than record capacity");
     return PFAC_OK;
 }
@@ -1439,7 +1490,7 @@ int pfac_scan_info(pfac_ctx *ctx, int *variant, int *tile_bytes, int *grid_block
     if (variant) *variant = ctx->variant;
     if (tile_bytes) *tile_bytes = WTILE;
     if (grid_blocks) *grid_blocks = ctx->grid_blocks;
-    if (lds_bytes) *lds_bytes = ctx->lds_bytes;
+    if (lds_bytes) *lds_bytes = (ctx->dense && ctx->stage_cap_d) ? ctx->lds_bytes_d : ctx->lds_bytes;
     return PFAC_OK;
 }
 
