@@ -73,7 +73,7 @@ constexpr int NBUF = 3;                    // staging buffers: a tile's records 
 constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
 // Dense mode (most tiles hold more matches than CAPW, e.g. a dictionary on text): ONE big staging buffer per
 // wave and synchronous emission -- fewer waves fit, but a tile is walked once instead of twice.
-constexpr int CAPW_DENSE = 3072;
+constexpr int CAPW_DENSE = 2048;
 constexpr int PW_FIXED_DENSE = WTILE + QCAP * 2 + CAPW_DENSE * 4;
 
 constexpr unsigned long long ST_AGG = 1ull << 62;
