@@ -27,7 +27,8 @@
  * There is no CPU matching path in this program: without a GPU it fails.
  *
  * Environment: PFAC_GPUS=n limits the number of GPUs used; PFAC_CHUNK_MB sets
- * the chunk size (default 256); PFAC_EMIT_THREADS the emitter's formatter threads.
+ * the chunk size (default 256); PFAC_EMIT_THREADS the emitter's formatter threads;
+ * PFAC_READ_THREADS the threads that pread() one chunk (default: cores / GPUs, at most 8).
  */
 #define _FILE_OFFSET_BITS 64
 #include "pfac.h"
@@ -57,6 +58,7 @@ typedef struct {
     uint64_t chunk_bytes, halo;
     chunk_t *chunks;                /* all chunks; this worker takes k = device, device + n_gpu, ... */
     int n_chunks;
+    int read_threads;               /* threads that pread() one chunk into the pinned staging buffer */
     double kernel_ms;
     int rc;
     char err[256];
@@ -92,6 +94,40 @@ static int read_fully(int fd, void *dst, uint64_t n, uint64_t off) {
         p += r; off += (uint64_t)r; n -= (uint64_t)r;
     }
     return 0;
+}
+
+/* One chunk is read by several threads, each pread()ing a 4 KiB-aligned slice: a single thread copies
+ * out of the page cache at ~5 GB/s, far below what the H2D link and the scan take. */
+typedef struct { int fd; unsigned char *dst; uint64_t n, off; int rc; } read_job;
+
+static void *read_part(void *arg) {
+    read_job *j = (read_job *)arg;
+    j->rc = read_fully(j->fd, j->dst, j->n, j->off);
+    return NULL;
+}
+
+static int read_parallel(int fd, void *dst, uint64_t n, uint64_t off, int n_threads) {
+    enum { MAX_READERS = 32 };
+    if (n_threads > MAX_READERS) n_threads = MAX_READERS;
+    if (n_threads < 2 || n < (uint64_t)n_threads * (64u << 10)) return read_fully(fd, dst, n, off);
+    read_job job[MAX_READERS];
+    pthread_t th[MAX_READERS];
+    int started[MAX_READERS];
+    const uint64_t part = ((n + (uint64_t)n_threads - 1) / (uint64_t)n_threads + 4095) & ~4095ull;
+    int used = 0, rc = 0;
+    for (uint64_t at = 0; at < n; at += part, used++) {
+        read_job *j = &job[used];
+        j->fd = fd; j->dst = (unsigned char *)dst + at; j->off = off + at; j->rc = 0;
+        j->n = n - at < part ? n - at : part;
+        started[used] = used > 0 && pthread_create(&th[used], NULL, read_part, j) == 0;
+    }
+    for (int i = 0; i < used; i++)          /* slice 0, and any slice whose thread did not start, is read here */
+        if (!started[i]) read_part(&job[i]);
+    for (int i = 0; i < used; i++) {
+        if (started[i]) pthread_join(th[i], NULL);
+        if (job[i].rc) rc = -1;
+    }
+    return rc;
 }
 
 /* finish the chunk that occupies `slot`: wait, fetch count, (re-scan on overflow), copy records back, publish */
@@ -153,7 +189,7 @@ static void *worker(void *arg) {
         const int stop = g_failed;
         pthread_mutex_unlock(&g_mu);
         if (stop) break;
-        if (read_fully(w->fd, stage[slot], c->n_avail, c->base)) { fail(w, NULL, PFAC_E_IO, "short read on the input file"); break; }
+        if (read_parallel(w->fd, stage[slot], c->n_avail, c->base, w->read_threads)) { fail(w, NULL, PFAC_E_IO, "short read on the input file"); break; }
         if ((rc = pfac_slot_h2d(ctx, slot, stage[slot], c->n_avail, 0))) { fail(w, ctx, rc, "h2d"); break; }
         if ((rc = pfac_scan_async(ctx, slot, NULL, c->n_owned, c->n_avail, NULL, 0))) { fail(w, ctx, rc, "scan"); break; }
         busy[slot] = k;
@@ -229,13 +265,18 @@ int main(int argc, char *argv[]) {
     int emit_threads = ncpu > 16 ? 16 : (ncpu < 1 ? 1 : (int)ncpu);
     if (getenv("PFAC_EMIT_THREADS")) emit_threads = atoi(getenv("PFAC_EMIT_THREADS"));
 
+    int read_threads = (int)(ncpu / n_gpu);
+    if (read_threads > 8) read_threads = 8;
+    if (getenv("PFAC_READ_THREADS")) read_threads = atoi(getenv("PFAC_READ_THREADS"));
+    if (read_threads < 1) read_threads = 1;
+
     double t2 = now_ms();
     worker_t *ws = (worker_t *)calloc((size_t)n_gpu, sizeof(worker_t));
     pthread_t *th = (pthread_t *)malloc((size_t)n_gpu * sizeof(pthread_t));
     for (int g = 0; g < n_gpu; g++) {                            /* one host thread per GPU, main.cc:180-241 */
         worker_t *w = &ws[g];
         w->device = g; w->n_gpu = n_gpu; w->n_streams = streamnum; w->blob = blob; w->blob_words = words;
-        w->fd = fd; w->chunk_bytes = chunk; w->halo = halo; w->chunks = chunks; w->n_chunks = n_chunks;
+        w->fd = fd; w->chunk_bytes = chunk; w->halo = halo; w->chunks = chunks; w->n_chunks = n_chunks; w->read_threads = read_threads;
         pthread_create(&th[g], NULL, worker, w);
     }
     /* emitter: chunks in input order == position order; records of a chunk are already sorted */

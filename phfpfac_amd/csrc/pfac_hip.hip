@@ -9,24 +9,30 @@
  * over); this kernel emits compact, globally ORDERED 8-byte records in a
  * single pass over the input.
  *
- * Kernel structure (one persistent 256-thread workgroup = 4 waves):
- *   ticket   tiles (16 KiB of input) are handed out in order by one atomic,
- *            so a workgroup holding tile t knows tiles < t are running or done
- *   stage    each wave loads its own 4 KiB with 16-B-per-lane buffer loads
- *            (hardware bounds check -> bytes past n_avail read as 0) and
- *            mirrors them + the max_pat_len-1 halo into LDS
- *   root     per byte one LDS lookup in a 256-entry "root has an edge" flag
- *            table -> 16-bit survivor mask per lane          (mk.cu:41)
- *   compact  wave prefix sum packs survivors' positions into an LDS queue, so
- *            the walk runs on dense lanes instead of 1-in-13 active ones
- *   walk     state = PHF(state, byte) from LDS (small tables) or L2 (large)
- *            until dead or out of input; final states are counted (mk.cu:49-71)
- *   order    tile match counts go through a decoupled look-back (single-pass
- *            chained scan over 8-byte {flag,value} words, agent-scope relaxed
- *            atomics) -> every tile learns its first record index
- *   emit     survivors are walked again and write (pos, state) records at
- *            base + wave prefix, i.e. sorted by (position, pattern length),
- *            which is exactly the reference's output order (main.cc:341-349)
+ * Kernel structure (one persistent workgroup per CU = up to 15 compute waves + 1 coordinator wave;
+ * the unit of work is a WAVE TILE, 4 KiB of input owned by one wavefront; no workgroup barrier in the loop):
+ *   ticket   the coordinator takes one BATCH of tiles (one per compute wave) per round with a single
+ *            global atomic, three rounds ahead; batches are handed out in order, so whoever holds
+ *            batch G knows every batch < G is held by a running workgroup
+ *   stage    each wave loads its 4 KiB with 16-B-per-lane buffer loads (hardware bounds check ->
+ *            bytes past n_avail read as 0), one round ahead, and mirrors them + the max_pat_len-1
+ *            halo into its private LDS region
+ *   root     16-bit "has a root edge" mask per lane per 16 bytes: SWAR compare + v_dot4 when the root
+ *            has a single edge, else one LDS flag lookup per byte                    (mk.cu:41)
+ *   compact  DPP prefix sums append the survivors' positions, in order, to a FIFO in LDS; a round of
+ *            64 (x NWALK) survivors runs whenever that many are pending, so lanes stay dense
+ *   walk     straight-line, predicated: root row and the dense depth-1 rows from LDS, deeper states
+ *            through the perfect hash  state = PHF(state, byte)  from LDS (small tables) or L2
+ *            (large); final states are recorded as they are met                     (mk.cu:49-71)
+ *   stage    records (pos:12 | state:20) go to an LDS staging buffer in (position, length) order
+ *   order    per-wave counts -> coordinator -> batch aggregate -> decoupled look-back over batches
+ *            (8-byte {flag,value} words, relaxed agent-scope atomics), pipelined over three rounds;
+ *            the coordinator writes every wave's first record index back to LDS
+ *   emit     two rounds later the wave copies its staged records to global memory, 16 B per lane --
+ *            globally sorted by (position, pattern length), the reference's output order
+ *            (main.cc:341-349).  Tiles with more records than the staging buffer holds are
+ *            re-walked writing straight to global memory; "dense mode" (one big staging buffer,
+ *            synchronous emission) takes over when most tiles are like that.
  */
 #include <hip/hip_runtime.h>
 

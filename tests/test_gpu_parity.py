@@ -76,7 +76,8 @@ def test_gphf_cli_config1(resolve, tmp_path):
     big = tmp_path / "big.txt"
     n = 6 * (1 << 20) + 12345
     big.write_bytes(tiled_bytes(n + 1, para).tobytes())        # + the byte the CLI drops (main.cc:138)
-    subprocess.check_call([exe, resolve("xaa"), "3", "1024", str(big)], cwd=tmp_path, env=env, stdout=subprocess.DEVNULL)
+    env5 = dict(env, PFAC_READ_THREADS="5")                    # every chunk pread() in 5 slices by 5 threads
+    subprocess.check_call([exe, resolve("xaa"), "3", "1024", str(big)], cwd=tmp_path, env=env5, stdout=subprocess.DEVNULL)
     o = Oracle(resolve("xaa"), 1, 1)
     exp = tmp_path / "expected.txt"
     o.emit(tiled_bytes(n, para), str(exp), spec=True)
