@@ -87,6 +87,16 @@ int pfac_table_build_file(const char *pattern_file, int width, pfac_table **out,
 int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len);
 /* Same as pfac_table_build_file, from a memory image of a pattern file. */
 int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len);
+/* Pattern-partition mode -- the reference's own multi-GPU scheme (create_table_reorder.c:217-247), kept as a
+ * fallback for automata that outgrow L2/MALL: the table of partition `part` of `n_parts` of the SORTED pattern
+ * list (k = n / P patterns each, the last one also takes n % P; ids stay whole-file line numbers, max_pat_len
+ * stays the global maximum).  A cut never separates identical lines, so duplicates resolve inside one
+ * partition ("last line wins") instead of overflowing result slots as main.cc:308-315 does.  Every partition
+ * scans the whole input; pfac_merge_partitions() below is the merge of main.cc:304-324. */
+int pfac_table_build_file_part(const char *pattern_file, int width, int part, int n_parts, pfac_table **out, char *err,
+                               size_t err_len);
+int pfac_table_build_mem_part(const void *patterns, size_t n_bytes, int width, int part, int n_parts, pfac_table **out,
+                              char *err, size_t err_len);
 void pfac_table_free(pfac_table *t);
 
 /* The device lookup evaluated on the host (property tests; never used on the scan path). */
@@ -116,12 +126,20 @@ typedef struct pfac_record {
     uint32_t pos;       /* start offset, relative to the first byte of the scanned range */
     uint32_t state;     /* final state reached (== index into idmap) */
 } pfac_record;
+/* idmap == NULL: rec.state already holds the pattern id (the output of pfac_merge_partitions). */
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap);
 /* Same bytes, produced by n_threads host threads (size pass, prefix sum, format + pwrite in place); the serial
  * fprintf loop is the end-to-end wall once the scan runs at TB/s.  The file must be seekable; falls back to the
  * serial emitter for small n, n_threads < 2 or pipes. */
 int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
                              int n_threads);
+/* Merge of per-partition match lists, replaces main.cc:304-324.  lists[k] (counts[k] records, sorted by
+ * position as the scan emits them) comes from partition k of pfac_table_build_file_part(); the result is
+ * ordered by (position, partition) -- i.e. by (position, pattern length), the reference's output order -- and
+ * its `state` field holds the PATTERN ID: idmaps[k][state] (idmaps == NULL or idmaps[k] == NULL: the list
+ * already holds ids).  Returns the number of records written, PFAC_E_OVERFLOW if out_cap is too small. */
+int64_t pfac_merge_partitions(const pfac_record *const *lists, const uint64_t *counts, const int32_t *const *idmaps,
+                              int n_parts, pfac_record *out, uint64_t out_cap);
 
 /* ------------------------------------------------------------------ */
 /* Device side (libpfac_hip.so): the master_kernel.cu path.            */

@@ -65,7 +65,8 @@ class CThreadData(C.Structure):
 
 
 HOST_SYMBOLS = (
-    "pfac_table_build_file", "pfac_table_build_file_escaped", "pfac_table_build_mem", "pfac_table_free", "pfac_table_lookup",
+    "pfac_table_build_file", "pfac_table_build_file_escaped", "pfac_table_build_mem", "pfac_table_build_file_part",
+    "pfac_table_build_mem_part", "pfac_merge_partitions", "pfac_table_free", "pfac_table_lookup",
     "pfac_table_blob_words", "pfac_table_to_blob", "pfac_table_from_blob", "pfac_table_from_reference_arrays",
     "pfac_emit_records", "pfac_emit_records_mt",
 )
@@ -94,6 +95,11 @@ def host_lib() -> C.CDLL:
         L.pfac_table_build_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(TP), C.c_char_p, C.c_size_t]
         L.pfac_table_build_file_escaped.argtypes = [C.c_char_p, C.c_int, C.POINTER(TP), C.c_char_p, C.c_size_t]
         L.pfac_table_build_mem.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(TP), C.c_char_p, C.c_size_t]
+        L.pfac_table_build_file_part.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(TP), C.c_char_p, C.c_size_t]
+        L.pfac_table_build_mem_part.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(TP), C.c_char_p,
+                                                C.c_size_t]
+        L.pfac_merge_partitions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+        L.pfac_merge_partitions.restype = C.c_int64
         L.pfac_table_free.argtypes = [TP]
         L.pfac_table_free.restype = None
         L.pfac_table_lookup.argtypes = [TP, C.c_int32, C.c_int32]

@@ -195,12 +195,14 @@ static int build_phf(pfac_table *t, const edge_t *edges, int32_t n_edges, char *
 }
 
 /* sort + trie + PHF over n patterns (ids and bytes filled in by a reader; pats is consumed) */
-static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_t max_len, int width, pfac_table **out,
-                               char *err, size_t err_len);
+static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_t max_len, int width, int part,
+                               int n_parts, pfac_table **out, char *err, size_t err_len);
 
-int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len) {
+static int build_mem_part(const void *patterns, size_t n_bytes, int width, int part, int n_parts, pfac_table **out,
+                          char *err, size_t err_len) {
     if (!patterns || !out) { set_err(err, err_len, "null argument%ld", 0); return PFAC_E_ARG; }
     *out = NULL;
+    if (n_parts < 1 || part < 0 || part >= n_parts) { set_err(err, err_len, "bad partition index %ld", part); return PFAC_E_ARG; }
     if (!is_pow2(width) || width > PFAC_COL_MAX) {
         set_err(err, err_len, "PHF width %ld must be a power of two <= 4096", width); return PFAC_E_ARG;
     }
@@ -228,7 +230,16 @@ int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_t
         n++;
         start = i + 1;
     }
-    return build_from_patterns(pats, n, n_bytes - n_lines, max_len, width, out, err, err_len);
+    return build_from_patterns(pats, n, n_bytes - n_lines, max_len, width, part, n_parts, out, err, err_len);
+}
+
+int pfac_table_build_mem(const void *patterns, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len) {
+    return build_mem_part(patterns, n_bytes, width, 0, 1, out, err, err_len);
+}
+
+int pfac_table_build_mem_part(const void *patterns, size_t n_bytes, int width, int part, int n_parts, pfac_table **out,
+                              char *err, size_t err_len) {
+    return build_mem_part(patterns, n_bytes, width, part, n_parts, out, err, err_len);
 }
 
 /*
@@ -328,22 +339,45 @@ int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_tabl
     if (rc) { free(pats); free(offs); free(arena); return rc; }
     for (size_t i = 0; i < n; i++) pats[i].pat = arena + offs[i];
     free(offs);
-    rc = build_from_patterns(pats, n, total, max_len, width, out, err, err_len);
+    rc = build_from_patterns(pats, n, total, max_len, width, 0, 1, out, err, err_len);
     free(arena);
     return rc;
 }
 
-static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_t max_len, int width, pfac_table **out,
-                               char *err, size_t err_len) {
+static int same_bytes(const pat_t *a, const pat_t *b) {
+    return a->len == b->len && memcmp(a->pat, b->pat, (size_t)a->len) == 0;
+}
+
+static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_t max_len, int width, int part,
+                               int n_parts, pfac_table **out, char *err, size_t err_len) {
     pat_t *tmp = (pat_t *)malloc((n ? n : 1) * sizeof(pat_t));
     if (!tmp) { free(pats); set_err(err, err_len, "out of memory (%ld patterns)", (long)n); return PFAC_E_NOMEM; }
     merge_sort(pats, tmp, n);
     free(tmp);
+    pat_t *const all = pats;                   /* what gets freed */
+    if (n_parts > 1) {
+        /* Pattern partitioning as the reference does it (create_table_reorder.c:217-247): the SORTED list is cut
+         * into P runs of k = n / P patterns, the last one also takes the n % P left over; ids stay the 1-based line
+         * numbers of the whole file and max_pat_len stays the global maximum (ctr.c:238,246).  One difference, on
+         * purpose: a cut never separates identical strings (it moves past them), so "the last line wins"
+         * (ctr.c:366) is decided inside one partition -- the reference lets such duplicates overflow the
+         * position's result slots (main.cc:308-315), which is outside the parity domain. */
+        const size_t k = n / (size_t)n_parts;
+        size_t lo = (size_t)part * k;
+        size_t hi = part == n_parts - 1 ? n : lo + k;
+        while (lo > 0 && lo < n && same_bytes(&pats[lo - 1], &pats[lo])) lo++;
+        while (hi > 0 && hi < n && same_bytes(&pats[hi - 1], &pats[hi])) hi++;
+        if (hi < lo) hi = lo;
+        pats += lo;
+        n = hi - lo;
+        total_bytes = 0;
+        for (size_t i = 0; i < n; i++) total_bytes += (size_t)pats[i].len;
+    }
 
     /* ---- trie as an edge list (LCP stack over the sorted list) ---- */
     if ((int64_t)n + 2 + (int64_t)total_bytes > INT32_MAX / 256) {
         /* keys are (state<<8)+ch in int32 on the device (master_kernel.cu:52) */
-        free(pats); set_err(err, err_len, "automaton too large (%ld pattern bytes)", (long)total_bytes); return PFAC_E_PATTERN;
+        free(all); set_err(err, err_len, "automaton too large (%ld pattern bytes)", (long)total_bytes); return PFAC_E_PATTERN;
     }
     edge_t *edges = (edge_t *)malloc((total_bytes + 1) * sizeof(edge_t));
     int32_t *path = (int32_t *)malloc((PFAC_MAX_PATTERN_LEN + 1) * sizeof(int32_t));
@@ -351,7 +385,7 @@ static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_
     pfac_table *t = (pfac_table *)calloc(1, sizeof *t);
     int32_t *idmap = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
     if (!edges || !path || !path_edge || !t || !idmap) {
-        free(pats); free(edges); free(path); free(path_edge); free(t); free(idmap);
+        free(all); free(edges); free(path); free(path_edge); free(t); free(idmap);
         set_err(err, err_len, "out of memory (%ld bytes)", (long)total_bytes); return PFAC_E_NOMEM;
     }
     const int32_t root = (int32_t)n + 1;
@@ -388,7 +422,7 @@ static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_
         }
         prev = cur;
     }
-    free(path); free(path_edge); free(pats);
+    free(path); free(path_edge); free(all);
 
     t->width = width;
     for (t->width_bit = 0; (width >> t->width_bit) != 1; t->width_bit++) ;
@@ -410,7 +444,8 @@ static int build_from_patterns(pat_t *pats, size_t n, size_t total_bytes, int32_
     return PFAC_OK;
 }
 
-int pfac_table_build_file(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len) {
+int pfac_table_build_file_part(const char *pattern_file, int width, int part, int n_parts, pfac_table **out, char *err,
+                               size_t err_len) {
     if (!pattern_file || !out) return PFAC_E_ARG;
     FILE *f = fopen(pattern_file, "rb");
     if (!f) { if (err && err_len) snprintf(err, err_len, "cannot open pattern file %s", pattern_file); return PFAC_E_IO; }
@@ -421,9 +456,13 @@ int pfac_table_build_file(const char *pattern_file, int width, pfac_table **out,
     if (!buf) { fclose(f); return PFAC_E_NOMEM; }
     if (sz > 0 && fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); return PFAC_E_IO; }
     fclose(f);
-    int rc = pfac_table_build_mem(buf, sz > 0 ? (size_t)sz : 0, width, out, err, err_len);
+    int rc = build_mem_part(buf, sz > 0 ? (size_t)sz : 0, width, part, n_parts, out, err, err_len);
     free(buf);
     return rc;
+}
+
+int pfac_table_build_file(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len) {
+    return pfac_table_build_file_part(pattern_file, width, 0, 1, out, err, err_len);
 }
 
 int32_t pfac_table_lookup(const pfac_table *t, int32_t state, int32_t ch) {
@@ -528,7 +567,7 @@ static inline char *put_uint(char *p, uint64_t v, int min_width) {
 }
 
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap) {
-    if (!file || (!rec && n) || !idmap) return PFAC_E_ARG;
+    if (!file || (!rec && n)) return PFAC_E_ARG;
     FILE *f = (FILE *)file;
     enum { CHUNK = 1 << 16, LINE_MAX_BYTES = 64 };
     char *buf = (char *)malloc((size_t)CHUNK * LINE_MAX_BYTES);
@@ -541,7 +580,7 @@ int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64
             memcpy(p, "At position ", 12); p += 12;
             p = put_uint(p, base + rec[k].pos, 4);                /* %4d */
             memcpy(p, ", match pattern ", 16); p += 16;
-            int32_t id = idmap[rec[k].state];
+            int32_t id = idmap ? idmap[rec[k].state] : (int32_t)rec[k].state;
             if (id < 0) { *p++ = '-'; p = put_uint(p, (uint64_t)(-(int64_t)id), 1); }
             else p = put_uint(p, (uint64_t)id, 1);                /* %d */
             *p++ = '\n';
@@ -552,6 +591,53 @@ int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64
     }
     free(buf);
     return total;
+}
+
+/* ---- pattern-partition mode: merge of the per-partition match lists, the reference's
+ * host merge (main.cc:304-324) on compact records.  There partition p's ids are appended, p ascending, after
+ * whatever position i's slots already hold; the partitions are consecutive runs of the SORTED pattern list and
+ * all patterns matching at one position are prefixes of one another, so that order is (position, pattern
+ * length) again.  Here: K lists sorted by position -> one list ordered by (position, partition), stable inside
+ * a partition; the output's `state` field holds the PATTERN ID (idmaps[k] applied; NULL = already ids). ---- */
+int64_t pfac_merge_partitions(const pfac_record *const *lists, const uint64_t *counts, const int32_t *const *idmaps,
+                              int n_parts, pfac_record *out, uint64_t out_cap) {
+    if (n_parts < 0 || (n_parts && (!lists || !counts))) return PFAC_E_ARG;
+    uint64_t total = 0;
+    for (int k = 0; k < n_parts; k++) {
+        if (counts[k] && !lists[k]) return PFAC_E_ARG;
+        total += counts[k];
+    }
+    if (total > out_cap) return PFAC_E_OVERFLOW;
+    if (total && !out) return PFAC_E_ARG;
+    uint64_t *head = (uint64_t *)calloc(n_parts ? (size_t)n_parts : 1, sizeof(uint64_t));
+    if (!head) return PFAC_E_NOMEM;
+    uint64_t w = 0;
+    while (w < total) {
+        /* best = smallest (pos, partition) among the heads; limit = the runner-up: a whole run is copied at once */
+        int best = -1, next = -1;
+        for (int k = 0; k < n_parts; k++) {
+            if (head[k] >= counts[k]) continue;
+            const uint32_t p = lists[k][head[k]].pos;
+            if (best < 0 || p < lists[best][head[best]].pos) { next = best; best = k; }
+            else if (next < 0 || p < lists[next][head[next]].pos) next = k;
+        }
+        const pfac_record *src = lists[best];
+        const int32_t *im = idmaps ? idmaps[best] : NULL;
+        uint64_t h = head[best];
+        if (next < 0) {
+            for (; h < counts[best]; h++, w++) { out[w].pos = src[h].pos; out[w].state = im ? (uint32_t)im[src[h].state] : src[h].state; }
+        } else {
+            /* records of `best` go first while pos < limit, or pos == limit and best is the earlier partition */
+            const uint32_t lim = lists[next][head[next]].pos;
+            for (; h < counts[best] && (src[h].pos < lim || (src[h].pos == lim && best < next)); h++, w++) {
+                out[w].pos = src[h].pos;
+                out[w].state = im ? (uint32_t)im[src[h].state] : src[h].state;
+            }
+        }
+        head[best] = h;
+    }
+    free(head);
+    return (int64_t)total;
 }
 
 /* ---- parallel text emitter (once the scan runs at TB/s the serial fprintf loop of
@@ -592,7 +678,7 @@ static void *emit_worker(void *arg) {
             uint64_t bytes = 0;
             for (uint64_t k = k0; k < k1; k++) {
                 const int dp = ndigits(j->base + j->rec[k].pos);
-                const int32_t id = j->idmap[j->rec[k].state];
+                const int32_t id = j->idmap ? j->idmap[j->rec[k].state] : (int32_t)j->rec[k].state;
                 const int di = id < 0 ? 1 + ndigits((uint64_t)(-(int64_t)id)) : ndigits((uint64_t)id);
                 bytes += 12 + (uint64_t)(dp < 4 ? 4 : dp) + 16 + (uint64_t)di + 1;
             }
@@ -603,7 +689,7 @@ static void *emit_worker(void *arg) {
                 memcpy(p, "At position ", 12); p += 12;
                 p = put_uint(p, j->base + j->rec[k].pos, 4);
                 memcpy(p, ", match pattern ", 16); p += 16;
-                const int32_t id = j->idmap[j->rec[k].state];
+                const int32_t id = j->idmap ? j->idmap[j->rec[k].state] : (int32_t)j->rec[k].state;
                 if (id < 0) { *p++ = '-'; p = put_uint(p, (uint64_t)(-(int64_t)id), 1); }
                 else p = put_uint(p, (uint64_t)id, 1);
                 *p++ = '\n';
@@ -623,7 +709,7 @@ static void *emit_worker(void *arg) {
 
 int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
                              int n_threads) {
-    if (!file || (!rec && n) || !idmap) return PFAC_E_ARG;
+    if (!file || (!rec && n)) return PFAC_E_ARG;
     if (n_threads < 2 || n < 4 * (uint64_t)EMIT_BLOCK) return pfac_emit_records(file, rec, n, base, idmap);
     if (n_threads > 64) n_threads = 64;
     FILE *f = (FILE *)file;

@@ -12,7 +12,14 @@ read-only tables, so shards are independent units:
   gives every rank its record offset; records are gathered to one rank only when a single ordered
   stream is wanted (``gather_records``) -- rank order == position order, so concatenation is sorted.
 
-No data-path collective touches the input bytes.  All functions work with the ``gloo`` backend on CPU
+No data-path collective touches the input bytes.
+
+Fallback, for automata that outgrow L2/MALL: the reference's own scheme, PATTERN
+partitioning -- rank g builds the table of partition g (``PfacTable.from_file_part``), the input is replicated with
+one broadcast (``broadcast_input``), every rank scans all of it, and ``gather_partition_matches`` merges the ranks'
+match lists by (position, partition) on one rank, which is the reference's host merge (main.cc:304-324).
+
+All functions work with the ``gloo`` backend on CPU
 tensors as well (that is how tests/test_dist_cpu.py exercises them with world_size 2).
 """
 from __future__ import annotations
@@ -23,7 +30,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .table import RECORD_DTYPE, PfacTable
+from .table import RECORD_DTYPE, PfacTable, merge_partitions
 
 ALIGN = 16
 
@@ -128,3 +135,39 @@ def split_gathered(gathered: torch.Tensor, counts: List[int], n_total: int, worl
         out["pos"][k: k + counts[r]] = raw["pos"][k: k + counts[r]].astype(np.uint64) + np.uint64(lo)
         k += counts[r]
     return out
+
+
+# ---------------------------------------------------------------------------
+# pattern-partition mode (the reference's scheme, create_table_reorder.c:217-247 + main.cc:304-324)
+
+def broadcast_input(data: Optional[torch.Tensor], device: torch.device, src: int = 0) -> torch.Tensor:
+    """Replicate the input bytes: rank ``src`` passes a uint8 tensor, every rank returns it on ``device``.
+    (The reference copies the whole input to every stream, master_kernel.cu:359; here it is ONE broadcast.)"""
+    rank = dist.get_rank()
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        if data is None:
+            raise ValueError("the source rank must pass the input")
+        n[0] = data.numel()
+    dist.broadcast(n, src)
+    buf = data.to(device).contiguous() if rank == src else torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src)
+    return buf
+
+
+def gather_partition_matches(records: np.ndarray, table: PfacTable, device: torch.device, dst: int = 0) -> Optional[np.ndarray]:
+    """``records``: this rank's (== this pattern partition's) records over the WHOLE input.  Returns on ``dst`` the
+    merged match list -- ordered by (position, partition) = (position, pattern length), ``state`` = pattern id --
+    and None elsewhere.  One count all-gather + one ordered record gather; the merge runs in the host library."""
+    world = dist.get_world_size()
+    ids = np.ascontiguousarray(records, dtype=RECORD_DTYPE).copy()
+    if ids.size:
+        ids["state"] = table.idmap[ids["state"]].astype(np.uint32)   # partitions number their final states separately
+    counts = gather_counts(ids.size, device)
+    t = torch.from_numpy(ids.view(np.int64)).to(device) if ids.size else torch.empty(0, dtype=torch.int64, device=device)
+    gathered = gather_records(t, ids.size, counts, dst=dst)
+    if gathered is None:
+        return None
+    raw = gathered.cpu().numpy().view(RECORD_DTYPE)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return merge_partitions([raw[offs[r]: offs[r + 1]] for r in range(world)], None)

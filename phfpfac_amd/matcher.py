@@ -172,6 +172,24 @@ class GpuMatcher:
         n = self.scan_resident(n_owned, n_avail, slot=slot)
         return self.records_to_host(n, slot)
 
+    def scan_partitioned(self, tables, data, slot: int = 0) -> np.ndarray:
+        """Pattern-partition mode on ONE GPU: the input is copied once, every partition's table (``tables[k]`` =
+        ``PfacTable.from_file_part(..., k, len(tables))``) scans it in turn, and the per-partition record lists are
+        merged as main.cc:304-324 does.  Returns records ordered by (position, pattern length) whose ``state``
+        field holds the PATTERN ID (emit with ``idmap=None``)."""
+        from .table import merge_partitions
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = int(buf.size)
+        self.reserve(slot, max(n, 1), max(n // 8, 4096))
+        if n:
+            self.h2d(buf, slot)
+        lists = []
+        for t in tables:
+            self.load_table(t)
+            cnt = self.scan_resident(n, n, slot=slot)
+            lists.append(self.records_to_host(cnt, slot))
+        return merge_partitions(lists, [t.idmap for t in tables])
+
     # -- synthetic inputs (device resident) --------------------------------
     def fill_tiled(self, d_dst, n: int, pattern: bytes, phase: int = 0, slot: int = 0) -> None:
         pat = np.frombuffer(pattern, dtype=np.uint8)

@@ -51,12 +51,25 @@ class PfacTable:
         return cls(ptr)
 
     @classmethod
-    def from_bytes(cls, patterns: bytes, width: int = 256) -> "PfacTable":
+    def from_bytes(cls, patterns: bytes, width: int = 256, part: int = 0, n_parts: int = 1) -> "PfacTable":
         L = host_lib()
         ptr = C.POINTER(CTable)()
         err = C.create_string_buffer(256)
         buf = C.create_string_buffer(patterns, len(patterns))
-        rc = L.pfac_table_build_mem(buf, len(patterns), int(width), C.byref(ptr), err, 256)
+        rc = L.pfac_table_build_mem_part(buf, len(patterns), int(width), int(part), int(n_parts), C.byref(ptr), err, 256)
+        if rc:
+            raise PfacError(rc, err.value.decode(errors="replace"))
+        return cls(ptr)
+
+    @classmethod
+    def from_file_part(cls, pattern_file: str, width: int, part: int, n_parts: int) -> "PfacTable":
+        """Partition ``part`` of ``n_parts`` of the sorted pattern list -- the reference's pattern partitioning
+        (create_table_reorder.c:217-247): every partition scans the whole input, ``merge_partitions`` merges."""
+        L = host_lib()
+        ptr = C.POINTER(CTable)()
+        err = C.create_string_buffer(256)
+        rc = L.pfac_table_build_file_part(os.fsencode(pattern_file), int(width), int(part), int(n_parts), C.byref(ptr),
+                                          err, 256)
         if rc:
             raise PfacError(rc, err.value.decode(errors="replace"))
         return cls(ptr)
@@ -116,17 +129,38 @@ class PfacTable:
             self._ptr = None
 
 
-def emit_records(path_or_file, records: np.ndarray, idmap: np.ndarray, base: int = 0, append: bool = False,
+def merge_partitions(record_lists, idmaps=None) -> np.ndarray:
+    """The reference's host merge (main.cc:304-324) on compact records: ``record_lists[k]`` are the position-sorted
+    records of pattern partition k; returns one array ordered by (position, partition) whose ``state`` field holds
+    the PATTERN ID (``idmaps[k]`` applied; None = the lists already hold ids)."""
+    L = host_lib()
+    lists = [np.ascontiguousarray(r, dtype=RECORD_DTYPE) for r in record_lists]
+    k = len(lists)
+    maps = [None if idmaps is None or m is None else np.ascontiguousarray(m, dtype=np.int32) for m in (idmaps or [None] * k)]
+    ptrs = (C.c_void_p * max(k, 1))(*[r.ctypes.data if r.size else None for r in lists])
+    counts = (C.c_uint64 * max(k, 1))(*[r.size for r in lists])
+    mptrs = (C.c_void_p * max(k, 1))(*[None if m is None else m.ctypes.data for m in maps])
+    total = sum(r.size for r in lists)
+    out = np.empty(total, dtype=RECORD_DTYPE)
+    n = L.pfac_merge_partitions(ptrs, counts, mptrs, k, out.ctypes.data, total)
+    if n != total:
+        raise PfacError(int(n), "pfac_merge_partitions")
+    return out
+
+
+def emit_records(path_or_file, records: np.ndarray, idmap, base: int = 0, append: bool = False,
                  threads: int = 1) -> int:
     """Write ``At position %4d, match pattern %d`` lines (main.cc:335-350).  Returns bytes written.
-    ``threads`` > 1 uses the parallel emitter (same bytes)."""
+    ``threads`` > 1 uses the parallel emitter (same bytes).  ``idmap`` None: ``records["state"]`` already holds
+    pattern ids (the output of ``merge_partitions``)."""
     L = host_lib()
     libc = C.CDLL(None)
     libc.fopen.restype = C.c_void_p
     libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
     libc.fclose.argtypes = [C.c_void_p]
     records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
-    idmap = np.ascontiguousarray(idmap, dtype=np.int32)
+    idmap = None if idmap is None else np.ascontiguousarray(idmap, dtype=np.int32)
+    idmap_ptr = None if idmap is None else idmap.ctypes.data
     libc.fseek.argtypes = [C.c_void_p, C.c_long, C.c_int]
     # append = open for update and seek to the end (an "a" stream is O_APPEND, which defeats positioned writes)
     f = libc.fopen(os.fsencode(path_or_file), b"r+b" if append and os.path.exists(path_or_file) else b"wb")
@@ -136,9 +170,9 @@ def emit_records(path_or_file, records: np.ndarray, idmap: np.ndarray, base: int
         libc.fseek(f, 0, 2)
     try:
         if threads > 1:
-            n = L.pfac_emit_records_mt(f, records.ctypes.data, records.size, int(base), idmap.ctypes.data, int(threads))
+            n = L.pfac_emit_records_mt(f, records.ctypes.data, records.size, int(base), idmap_ptr, int(threads))
         else:
-            n = L.pfac_emit_records(f, records.ctypes.data, records.size, int(base), idmap.ctypes.data)
+            n = L.pfac_emit_records(f, records.ctypes.data, records.size, int(base), idmap_ptr)
     finally:
         libc.fclose(f)
     if n < 0:

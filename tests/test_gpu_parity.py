@@ -85,6 +85,37 @@ def test_gphf_cli_config1(resolve, tmp_path):
     assert (tmp_path / "GPU_match_result.txt").read_bytes() == exp.read_bytes()
 
 
+@pytest.mark.parametrize("n_parts", [4, 7])
+def test_pattern_partition_mode_golden(n_parts, resolve, tmp_path):
+    """Pattern-partition fallback (the reference's own scheme, ctr.c:217-247 + main.cc:304-324): every partition's
+    table scans the whole input on the GPU, pfac_merge_partitions merges -> the same GPU_match_result.txt."""
+    c = FP["cases"]["all_x_1M_s1_w256"]
+    tabs = [PfacTable.from_file_part(resolve(c["pattern"]), 256, k, n_parts) for k in range(n_parts)]
+    data = open(resolve(c["input"]), "rb").read()[:-1]
+    with GpuMatcher(0, 1) as g:
+        merged = g.scan_partitioned(tabs, data)
+    out = tmp_path / "GPU_match_result.txt"
+    emit_records(str(out), merged, None)
+    blob = out.read_bytes()
+    assert merged.size == c["lines"] and len(blob) == c["bytes"]
+    assert hashlib.md5(blob).hexdigest() == c["md5"]
+
+
+def test_pattern_partition_mode_edge(resolve):
+    """More partitions than patterns (empty partitions scan with an edgeless root) and duplicates at a cut."""
+    pats = b"ab\nab\nabc\nb\nb\nca\n"
+    data = (b"abcab cabbabc" * 700)[:8191]
+    full = PfacTable.from_bytes(pats, 256)
+    one = gpu_records(full, data)
+    for n_parts in (2, 3, 9):
+        tabs = [PfacTable.from_bytes(pats, 256, part=k, n_parts=n_parts) for k in range(n_parts)]
+        with GpuMatcher(0, 1) as g:
+            merged = g.scan_partitioned(tabs, data)
+        assert merged.size == one.size
+        np.testing.assert_array_equal(merged["pos"], one["pos"])
+        np.testing.assert_array_equal(merged["state"].astype(np.int32), full.idmap[one["state"]])
+
+
 @pytest.mark.parametrize("width", [256, 64, 1024, 4096])
 def test_dictionary_vs_oracle_widths(width, resolve, work_dir):
     """7 989-word dictionary (tables via L2) on text, every PHF width: records == oracle, in order."""
