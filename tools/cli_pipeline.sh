@@ -24,7 +24,7 @@ for s in ${STREAMS:-1 4}; do
     (
       cd $W
       T0=$(date +%s.%N)
-      $OLDPWD/phfpfac_amd/bin/gphf $OLDPWD/$D/$p $s 256 $W/text1g | grep -E "^2\.|^3\.|^4\."
+      $OLDPWD/phfpfac_amd/bin/gphf $OLDPWD/$D/$p $s 256 $W/text1g | grep -E "^2\.|^3\.|^4\.|^5\."
       T1=$(date +%s.%N)
       python3 -c "print('wall %.2f s (whole program incl. table build, file read, emit)' % ($T1 - $T0))"
       ls -la GPU_match_result.txt | awk '{print "output bytes", $5}'
