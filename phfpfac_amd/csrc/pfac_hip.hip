@@ -56,7 +56,7 @@ constexpr int SUB = WAVE * 16;             // bytes one wave covers with one 16-
 constexpr int SUBS = 4;                    // such sub-tiles per wave tile
 constexpr int WTILE = SUB * SUBS;          // 4096: tile-local positions fit 12 bits
 constexpr int HALO_MAX = 1024;             // >= max_pat_len - 1 (patterns are < 1024 bytes), multiple of 16
-constexpr int QCAP = SUB / 2 + 2 * WAVE;   // survivor FIFO: < 128 carried over + up to 512 appended at a time
+constexpr int QCAP = SUB / 2 + 4 * WAVE;   // survivor FIFO: < one round (at most 4 x 64) carried over + up to 512 appended at a time
 #ifndef PFAC_CAPW
 #define PFAC_CAPW 384
 #endif
@@ -73,6 +73,8 @@ constexpr int SH_FTAB = SH_S0 + 256 * 4;
 constexpr int SH_D1IDX = SH_FTAB + 8 * 256; // 256 x u8: dense-row index of the depth-1 state reached on each root byte
 constexpr int SH_D1 = SH_D1IDX + 256;      // d1_rows dense rows int32[256] (the hot first-level transition rows)
 constexpr int D1_MAX = 32;                 // at most this many depth-1 states get a dense row (else none do)
+constexpr int D1_STATE_BITS = 20;          // packed dense-row entry (FUSED): state | index of its r[] << 20
+constexpr int D1_N2_MAX = 2048;            // ... so at most this many depth-2 states (the entry stays positive)
 // the PHF tables (variant 0) follow the dense rows: SH_D1 + d1_rows * 1024
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
 constexpr int NBUF = 3;                    // staging buffers: a tile's records are emitted two rounds later
@@ -97,12 +99,15 @@ struct ScanArgs {
     const int *s0;
     const int *r;
     const int2 *T;
+    const int4 *T4;                       // FUSED: {owner row, next state, r[row of next state], 0} per slot (tables via L2)
     int r_words, t_entries;
     int ht_size, wbit, num_final, halo;   // halo: bytes readable past a tile, multiple of 16
     int shared_bytes, pw_bytes;           // LDS carve: shared region, then one region per wave
     const int *d1;                        // dense rows of the depth-1 states, d1_rows x 256 (or null)
     const unsigned char *d1idx;           // root byte -> dense row index
     int d1_rows;                          // 0: no dense level
+    const int *d1r2;                      // FUSED + packed dense rows: r[] of the depth-2 states, d1_n2 words (else null)
+    int d1_n2;                            // > 0: a dense-row entry is  state | index into d1r2 << 20  (or -1)
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
     unsigned nbuf;                        // staging buffers per wave: 3 = emit two rounds late, 1 = emit at once (dense mode)
@@ -294,8 +299,8 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 }
 
 // NWALK independent walks per lane, stepped together.  Walk w starts at tile-local position pos[w];
-// n[w] counts the final states reached, m0[w] keeps the first one, m1[w] the latest one (== the second
-// when exactly two are met).  lim = first tile-local byte that may not be read.
+// n[w] counts the final states reached, m[w][..] keeps the first MREG of them (MREG = 2: the first and the
+// latest, == the second when exactly two are met).  lim = first tile-local byte that may not be read.
 //  * all lanes step in lock step (trip count = deepest walk in the wave); dead lanes are predicated with
 //    selects instead of nested divergent branches -- far fewer exec-mask / scalar instructions per step;
 //  * input bytes come four at a time from one aligned 8-byte LDS read, so a step's only dependent
@@ -303,16 +308,25 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 //  * NWALK = 2 (tables gathered through L2): every table round trip has an independent twin in flight --
 //    the memory-level parallelism of twice the occupancy without the LDS more waves would need.  With
 //    the tables in LDS a second walk buys nothing (measured), so NWALK = 1 there.
-template <bool W8, int NWALK>
+//  * FUSED (tables gathered through L2, PHF width >= 256): each slot also carries r[] of the state it leads to,
+//    so a step is ONE 16-byte gather instead of a 4-byte one (r) and a dependent 8-byte one (T) -- the
+//    dictionary-on-text regime is bound by the L2's request rate (every lane of a gather is its own request), and
+//    this halves the requests; only the first hashed step of a walk still looks r[] up.
+//  * NWALK = 4 (the dense-match regime on L2 tables, e.g. a dictionary on text): a walk there is a chain of L2
+//    round trips and the wave has nothing else to do, so four chains per lane run side by side; the first
+//    MREG = 4 final states of a walk stay in registers (two otherwise) -- a position where more patterns start
+//    costs a second, serial walk (walk_store).
+template <bool W8, int NWALK, bool FUSED, int MREG>
 __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, const unsigned char *d1idx,
-                                      const int *D1, bool dense1, const int *R, const int2 *T,
+                                      const int *D1, bool dense1, const int *D1R2, const int *R, const int2 *T, const int4 *T4,
                                       const unsigned (&pos)[NWALK], const bool (&active)[NWALK], unsigned lim, int wbit,
-                                      int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m0)[NWALK],
-                                      unsigned (&m1)[NWALK]) {
+                                      int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
+    static_assert(MREG == 2 || MREG == 4, "two or four final states per walk in registers");
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
     unsigned win[NWALK], p[NWALK], f[NWALK];
-    int s[NWALK];
+    int s[NWALK], rn[NWALK];                                   // rn: r[row of s] (FUSED)
     bool go[NWALK], seen[NWALK];
+    const int sub = wbit - 8;                                  // FUSED needs wbit >= 8: row = state >> sub
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
         const unsigned lo = t32[pos[w] >> 2], hi = t32[(pos[w] >> 2) + 1];   // may run a few bytes past lim: never used
@@ -323,9 +337,12 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         const int st = s0[win[w] & 0xFFu];
         f[w] = d1idx[win[w] & 0xFFu];                          // dense row of that state (when dense1)
         s[w] = active[w] ? st : -1;
-        n[w] = 0; m0[w] = 0; m1[w] = 0;
+        n[w] = 0;
+#pragma unroll
+        for (int k = 0; k < MREG; k++) m[w][k] = 0;
         p[w] = pos[w] + 1;
         go[w] = false; seen[w] = false;
+        rn[w] = 0;
     }
     // account for the states just reached; false when no lane of the wave can go on.
     // final <=> (unsigned)s < num_final, which also rejects the dead state -1.
@@ -334,9 +351,14 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
             const bool fin = (unsigned)s[w] < (unsigned)num_final;
-            m0[w] = (fin && !seen[w]) ? (unsigned)s[w] : m0[w];
-            m1[w] = fin ? (unsigned)s[w] : m1[w];
-            seen[w] = seen[w] || fin;
+            if (MREG == 2) {                                   // first and latest (== second when n == 2)
+                m[w][0] = (fin && !seen[w]) ? (unsigned)s[w] : m[w][0];
+                m[w][1] = fin ? (unsigned)s[w] : m[w][1];
+                seen[w] = seen[w] || fin;
+            } else {
+#pragma unroll
+                for (int k = 0; k < MREG; k++) m[w][k] = (fin && n[w] == (unsigned)k) ? (unsigned)s[w] : m[w][k];
+            }
             n[w] += fin ? 1u : 0u;
             go[w] = s[w] >= 0 && p[w] < lim;
             any = any || go[w];
@@ -346,6 +368,42 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     // one transition on byte number `bi` of the window (straight-line: dead lanes look up a harmless, valid slot)
     auto step = [&](int bi) {
         int row[NWALK], idx[NWALK];
+        if (FUSED) {
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) {
+                const int ch = (int)((win[w] >> (8 * bi)) & 0xFFu);
+                const int sg = go[w] ? s[w] : 0;
+                const int rg = go[w] ? rn[w] : 0;
+                if (W8) {
+                    row[w] = sg;
+                    idx[w] = rg + ch;
+                } else {
+                    row[w] = sg >> sub;
+                    idx[w] = rg + (((sg & ((1 << sub) - 1)) << 8) | ch);
+                }
+            }
+            int4 e[NWALK];
+            unsigned ic[NWALK];
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) {
+                ic[w] = min((unsigned)idx[w], (unsigned)ht_size - 1u);
+                if (NWALK == 4) {
+                    // the dense-match regime waits on the memory pipeline, not on instruction issue: dead lanes
+                    // stay out of the gather (every lane of a gather costs the texture path an address cycle)
+                    e[w] = make_int4(-1, -1, 0, 0);
+                    if (go[w]) e[w] = T4[ic[w]];
+                } else {
+                    e[w] = T4[ic[w]];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) {
+                s[w] = (go[w] && ic[w] == (unsigned)idx[w] && e[w].x == row[w]) ? e[w].y : -1;
+                rn[w] = e[w].z;
+                p[w]++;
+            }
+            return;
+        }
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
             const int ch = (int)((win[w] >> (8 * bi)) & 0xFFu);
@@ -372,19 +430,36 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             p[w]++;
         }
     };
+    // FUSED: the first hashed step of a walk has no slot to take r[] from
+    auto load_rn = [&]() {
+        if (FUSED) {
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) rn[w] = R[(go[w] ? s[w] : 0) >> sub];
+        }
+    };
     if (!reached()) return;
     if (dense1) {
         // second byte: the depth-1 state's row is dense in LDS -- one lookup, no hash, no owner check
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
             const int nx = D1[(go[w] ? f[w] : 0u) * 256u + ((win[w] >> 8) & 0xFFu)];
-            s[w] = go[w] ? nx : -1;
+            if (FUSED && D1R2) {
+                // packed entry: the depth-2 state and where its r[] sits in LDS -- the walk's first hashed step
+                // needs no r[] gather either
+                const bool ok = go[w] && nx >= 0;
+                s[w] = ok ? (nx & ((1 << D1_STATE_BITS) - 1)) : -1;
+                rn[w] = D1R2[ok ? (nx >> D1_STATE_BITS) : 0];
+            } else {
+                s[w] = go[w] ? nx : -1;
+            }
             p[w]++;
         }
     } else {
+        load_rn();
         step(1);
     }
     if (!reached()) return;
+    if (dense1 && !(FUSED && D1R2)) load_rn();
     step(2);
     if (!reached()) return;
     step(3);
@@ -444,60 +519,75 @@ struct Dense1 {
     const unsigned char *idx;
     const int *rows;
     bool on;
+    const int *r2;      // packed rows (FUSED): r[] of the depth-2 states, in LDS; null = plain rows
 };
 
 // One round: up to 64*NWALK survivors -- queue entries [q0, q0+nact), lane L takes entries L, L+64, ... walked
 // side by side -- append their records, in queue (= position) order, at index `wrun` of the staging
 // buffer (DIRECT == false) or of the global record array.  Returns the number of records.
-template <bool W8, bool DIRECT, int NWALK>
+template <bool W8, bool DIRECT, int NWALK, bool FUSED>
 __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
                                            const int *R, const int2 *T, const unsigned short *q, unsigned q0,
                                            unsigned nact, int lane, unsigned *stage, unsigned lim,
                                            unsigned long long tile_base, unsigned long long wrun) {
-    static_assert(NWALK == 1 || NWALK == 2, "one or two walks per lane");
+    static_assert(NWALK == 1 || NWALK == 2 || NWALK == 4, "one, two or four walks per lane");
+    constexpr int MREG = NWALK == 4 ? 4 : 2;
     bool active[NWALK];
-    unsigned pos[NWALK], n[NWALK], m0[NWALK], m1[NWALK];
+    unsigned pos[NWALK], n[NWALK], m[NWALK][MREG];
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
         active[w] = (unsigned)lane + WAVE * w < nact;
         pos[w] = active[w] ? q[q0 + WAVE * w + lane] : 0u;
     }
-    walkN<W8, NWALK>(tile, s0, d1.idx, d1.rows, d1.on, R, T, pos, active, lim, a.wbit, a.ht_size, a.num_final, n, m0, m1);
-    // one prefix sum for both halves (16-bit fields; a walk reports < 1024 matches)
-    const unsigned packed = NWALK == 2 ? (n[0] | (n[NWALK - 1] << 16)) : n[0];
-    const unsigned inc = wave_incl_scan(packed);
-    const unsigned last = bcast_last(inc);
-    const unsigned tot0 = NWALK == 2 ? (last & 0xFFFFu) : last;
-    const unsigned tot1 = NWALK == 2 ? (last >> 16) : 0u;
-    unsigned ex[NWALK];
-    ex[0] = (NWALK == 2 ? (inc & 0xFFFFu) : inc) - n[0];
-    if (NWALK == 2) ex[NWALK - 1] = tot0 + (inc >> 16) - n[NWALK - 1];
+    walkN<W8, NWALK, FUSED, MREG>(tile, s0, d1.idx, d1.rows, d1.on, d1.r2, R, T, a.T4, pos, active, lim, a.wbit, a.ht_size,
+                                  a.num_final, n, m);
+    // prefix sums of the counts, two walks per scan (16-bit fields; a walk reports < 1024 matches)
+    unsigned ex[NWALK], total = 0;
+#pragma unroll
+    for (int w0 = 0; w0 < NWALK; w0 += 2) {
+        const bool pair = w0 + 1 < NWALK;
+        const unsigned packed = pair ? (n[w0] | (n[pair ? w0 + 1 : w0] << 16)) : n[w0];
+        const unsigned inc = wave_incl_scan(packed);
+        const unsigned last = bcast_last(inc);
+        const unsigned t0 = pair ? (last & 0xFFFFu) : last;
+        ex[w0] = total + (pair ? (inc & 0xFFFFu) : inc) - n[w0];
+        total += t0;
+        if (pair) {
+            ex[w0 + 1] = total + (inc >> 16) - n[w0 + 1];
+            total += last >> 16;
+        }
+    }
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
+        const bool regs = n[w] <= (unsigned)MREG;              // every record of this walk is in registers
         if (DIRECT) {
             const unsigned long long ri = wrun + ex[w];
             pfac_record rec;
             rec.pos = (unsigned)(tile_base + pos[w]);
-            if (n[w] > 0 && ri < a.out_cap) { rec.state = m0[w]; a.out[ri] = rec; }
-            if (n[w] == 2 && ri + 1 < a.out_cap) { rec.state = m1[w]; a.out[ri + 1] = rec; }
-            if (n[w] > 2)
+            if (n[w] > 0 && ri < a.out_cap) { rec.state = m[w][0]; a.out[ri] = rec; }
+#pragma unroll
+            for (int k = 1; k < MREG; k++)
+                if (regs && n[w] > (unsigned)k && ri + k < a.out_cap) { rec.state = m[w][k]; a.out[ri + k] = rec; }
+            if (!regs)
                 walk_store<W8, true>(tile, s0, R, T, pos[w], lim, a.wbit, a.ht_size, a.num_final, nullptr, 0, a.out, a.out_cap, ri, rec.pos);
         } else {
             const unsigned ri = (unsigned)wrun + ex[w];        // tile-local record index: 32 bits are plenty
-            if (n[w] > 0 && ri < a.stage_cap) stage[ri] = pos[w] | (m0[w] << 12);
-            if (n[w] == 2 && ri + 1 < a.stage_cap) stage[ri + 1] = pos[w] | (m1[w] << 12);
-            if (n[w] > 2)
+            if (n[w] > 0 && ri < a.stage_cap) stage[ri] = pos[w] | (m[w][0] << 12);
+#pragma unroll
+            for (int k = 1; k < MREG; k++)
+                if (regs && n[w] > (unsigned)k && ri + k < a.stage_cap) stage[ri + k] = pos[w] | (m[w][k] << 12);
+            if (!regs)
                 walk_store<W8, false>(tile, s0, R, T, pos[w], lim, a.wbit, a.ht_size, a.num_final, stage, a.stage_cap, nullptr, 0, ri, 0);
         }
     }
-    return tot0 + tot1;
+    return total;
 }
 
 // Compaction + walk over one wave tile.  Survivors (set bits of the per-lane masks) are appended,
 // in position order, to a FIFO in LDS; whenever 64 are pending a full round runs, so lanes stay
 // busy even when only one offset in thirteen survives the root test.  Returns the tile's match
 // count; with DIRECT the records are written at global index wrun onwards.
-template <bool W8, bool DIRECT, int NWALK>
+template <bool W8, bool DIRECT, int NWALK, bool FUSED>
 __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
                                                         const Dense1 &d1, const int *R, const int2 *T, unsigned short *q,
                                                         unsigned *stage, const unsigned (&masks)[SUBS], int lane,
@@ -550,7 +640,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             constexpr unsigned RW = WAVE * NWALK;  // survivors per round
             unsigned h = 0;
             for (; h + RW <= tail; h += RW)
-                wrun += roundN<W8, DIRECT, NWALK>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
+                wrun += roundN<W8, DIRECT, NWALK, FUSED>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
             if (h) {                               // move the < RW left-overs to the front
                 const unsigned rem = tail - h;
                 unsigned short v[NWALK];
@@ -564,7 +654,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             }
         }
     }
-    if (tail) wrun += roundN<W8, DIRECT, NWALK>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun);
+    if (tail) wrun += roundN<W8, DIRECT, NWALK, FUSED>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun);
     return wrun;
 }
 
@@ -631,8 +721,11 @@ __device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned char
 // The scan kernel.  Workgroups share the read-only tables staged in LDS once; after that there is
 // no workgroup barrier: compute waves pipeline  [loads of round r+1 in flight | scan round r |
 // emit round r-1]  and meet the coordinator only through the LDS rings above.
-template <bool TLDS, bool W8, int ROOT>
-__global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(ScanArgs a) {
+constexpr int MAX_WAVES_NW4 = 10;          // four walks per lane need registers: at most 10 waves per workgroup (dense mode has 9-10)
+template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW>
+__global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLOCK)) void pfac_scan_kernel(ScanArgs a) {
+    static_assert(!(TLDS && FUSED), "the fused table is for tables gathered through L2");
+    static_assert(NW == (TLDS ? 1 : 2) || (FUSED && NW == 4), "walks per lane: 1 (LDS tables), 2 (L2 tables), 4 (L2, fused, dense matches)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *hdr = reinterpret_cast<unsigned *>(smem + SH_HDR);
     int *s0 = reinterpret_cast<int *>(smem + SH_S0);
@@ -659,8 +752,11 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
     } else {
         for (int i = tid; i < 256; i += blockDim.x) d1idx_l[i] = 0;
     }
-    const Dense1 d1 = {d1idx_l, d1_l, a.d1_rows > 0};
-    const int sh_tab = SH_D1 + a.d1_rows * 1024;
+    int *d1r2_l = reinterpret_cast<int *>(smem + SH_D1 + a.d1_rows * 1024);
+    if (FUSED && a.d1_n2 > 0)
+        for (int i = tid; i < a.d1_n2; i += blockDim.x) d1r2_l[i] = a.d1r2[i];
+    const Dense1 d1 = {d1idx_l, d1_l, a.d1_rows > 0, (FUSED && a.d1_n2 > 0) ? d1r2_l : nullptr};
+    const int sh_tab = SH_D1 + a.d1_rows * 1024;     // (the packed rows' r[] and LDS tables never coexist)
     const int *R = a.r;
     const int2 *T = a.T;
     if (TLDS) {
@@ -846,7 +942,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
         if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * a.stage_cap;
-        const unsigned long long cnt = tile_pass<W8, false, (TLDS ? 1 : 2)>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
+        const unsigned long long cnt = tile_pass<W8, false, NW, FUSED>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
         if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
         const bool overflow = cnt > a.stage_cap;
@@ -871,7 +967,7 @@ __global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(S
                 if (overflow)
                     // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
                     // while its bytes are still in LDS, writing straight to global memory
-                    tile_pass<W8, true, (TLDS ? 1 : 2)>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
+                    tile_pass<W8, true, NW, FUSED>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
                 else
                     copy_out(a, stage, (unsigned)cnt, base, tile_base, lane);   // dense mode: staged, emitted at once
             }
@@ -921,6 +1017,20 @@ __global__ void pfac_repack_kernel(const int *blob, int *s0, int *r, int2 *T, in
     for (int i = i0; i < num_final; i += stride) idmap[i] = b_id[i];
 }
 
+// Fused slots for tables gathered through L2 (PHF width >= 256): T4[i] = {owner row, next state, r[row of next], 0}.
+__global__ void pfac_fuse_kernel(const int2 *T, const int *r, int wbit, int ht_size, int max_row, int4 *T4) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ht_size; i += stride) {
+        const int2 e = T[i];
+        int rn = -1;
+        if (e.y >= 0) {
+            const int row = e.y >> (wbit - 8);
+            if (row < max_row) rn = r[row];
+        }
+        T4[i] = make_int4(e.x, e.y, rn, 0);
+    }
+}
+
 // Dense rows of the depth-1 states: row f, column c = lookup(state d1state[f], byte c) through the PHF.
 __global__ void pfac_build_d1_kernel(const int *d1state, const int *r, const int2 *T, int wbit, int ht_size, int *d1) {
     const int st = d1state[blockIdx.x];
@@ -934,6 +1044,18 @@ __global__ void pfac_build_d1_kernel(const int *d1state, const int *r, const int
         if (e.x == row) nx = e.y;
     }
     d1[blockIdx.x * 256 + c] = nx;
+}
+
+// FUSED: pack the dense rows in place -- entry = state | k << 20 with r2[k] = r[row of that state]; *counter hands out k.
+__global__ void pfac_pack_d1_kernel(int *d1, int n_entries, const int *r, int wbit, int max_row, int *r2, int *counter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    const int nx = d1[i];
+    if (nx < 0) return;
+    const int k = atomicAdd(counter, 1);
+    const int row = nx >> (wbit - 8);
+    r2[k] = row < max_row ? r[row] : -1;
+    d1[i] = nx | (k << D1_STATE_BITS);
 }
 
 __device__ __forceinline__ unsigned long long match_hash(unsigned long long pos, unsigned id) {
@@ -1019,10 +1141,12 @@ struct pfac_ctx {
     size_t tab_bytes = 0;
     int *d_s0 = nullptr, *d_r = nullptr, *d_idmap = nullptr;
     int2 *d_T = nullptr;
+    int4 *d_T4 = nullptr;                 // fused slots (variant 1, width >= 256), else null
     int width_bit = 0, num_final = 0, max_pat_len = 0, max_row = 0, ht_size = 0, state_num = 0;
     bool have_table = false;
     int variant = 1;
     const void *kernel = nullptr;
+    const void *kernel_d = nullptr;       // the kernel dense mode launches (four walks per lane on fused L2 tables)
     int lds_bytes = 0, shared_bytes = 0, pw_bytes = 0, halo = 0, waves_per_block = 0, root_mode = 0;
     unsigned root_byte = 0, stage_cap = 0;
     // the dense-mode twin of {pw_bytes, waves_per_block, lds_bytes, stage_cap}: one big staging buffer per wave
@@ -1032,6 +1156,7 @@ struct pfac_ctx {
     int dense_forced = -1;                // PFAC_DENSE=0/1 pins the mode
     int *d_d1 = nullptr;                  // dense depth-1 rows + (after them) the 256-byte row index
     int d1_rows = 0;
+    int d1_n2 = 0;                        // > 0: dense rows are packed (fused tables), r[] of the depth-2 states follows them
     int grid_blocks = 0;
     std::string err;
     std::mutex mu;
@@ -1086,9 +1211,14 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         if (s0_host[i] >= 0) { d1state[fan] = s0_host[i]; d1idx[i] = (unsigned char)(fan < 255 ? fan : 255); fan++; rb = i; }
     }
     ctx->d1_rows = (fan >= 1 && fan <= D1_MAX && !getenv("PFAC_NO_D1")) ? fan : 0;
+    // tables via L2 and PHF width >= 256: fused slots, one gather per step
+    const bool fused = ctx->variant == 1 && ctx->width_bit >= 8 && !getenv("PFAC_NO_FUSE");
+    ctx->d1_n2 = 0;
     if (ctx->d_d1) { HIP_TRY(ctx, hipFree(ctx->d_d1)); ctx->d_d1 = nullptr; }
     if (ctx->d1_rows) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_d1, (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4));
+        // layout: rows | 256-byte row index | the depth-1 states | (packed rows) r[] of the depth-2 states | counter
+        const size_t off_r2 = (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_d1, off_r2 + (size_t)D1_N2_MAX * 4 + 16));
         unsigned char *b = reinterpret_cast<unsigned char *>(ctx->d_d1);
         int *d_state = reinterpret_cast<int *>(b + (size_t)ctx->d1_rows * 1024 + 256);
         HIP_TRY(ctx, hipMemcpy(b + (size_t)ctx->d1_rows * 1024, d1idx, 256, hipMemcpyHostToDevice));
@@ -1097,8 +1227,25 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
                            ctx->width_bit, ctx->ht_size, ctx->d_d1);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipDeviceSynchronize());
+        if (fused && ctx->state_num <= (1 << D1_STATE_BITS) && !getenv("PFAC_NO_D1PACK")) {
+            // how many depth-2 states are there?  (host copy of the rows: at most 32 KiB)
+            std::vector<int> rows((size_t)ctx->d1_rows * 256);
+            HIP_TRY(ctx, hipMemcpy(rows.data(), ctx->d_d1, rows.size() * 4, hipMemcpyDeviceToHost));
+            int n2 = 0;
+            for (int v : rows) n2 += v >= 0;
+            if (n2 >= 1 && n2 <= D1_N2_MAX) {
+                int *r2 = reinterpret_cast<int *>(b + off_r2);
+                int *counter = r2 + D1_N2_MAX;
+                HIP_TRY(ctx, hipMemset(counter, 0, 4));
+                hipLaunchKernelGGL(pfac_pack_d1_kernel, dim3((unsigned)ctx->d1_rows), dim3(256), 0, 0, ctx->d_d1,
+                                   ctx->d1_rows * 256, ctx->d_r, ctx->width_bit, ctx->max_row, r2, counter);
+                HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipDeviceSynchronize());
+                ctx->d1_n2 = n2;
+            }
+        }
     }
-    ctx->shared_bytes = SH_D1 + ctx->d1_rows * 1024 + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : 0);
+    ctx->shared_bytes = SH_D1 + ctx->d1_rows * 1024 + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 4, 16));
     ctx->pw_bytes = (int)align_up((size_t)PW_FIXED + ctx->halo, 16);
     int nwb = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes + 1;     // compute waves + the coordinator (no LDS region)
     if (nwb > MAX_WAVES_PER_BLOCK) nwb = MAX_WAVES_PER_BLOCK;
@@ -1124,12 +1271,36 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->dense_forced = getenv("PFAC_DENSE") ? atoi(getenv("PFAC_DENSE")) : -1;
     ctx->dense = ctx->dense_forced == 1 && ctx->stage_cap_d;
     const bool w8 = ctx->width_bit == 8;
-    const void *k[2][2][2] = {
-        {{(const void *)pfac_scan_kernel<false, false, 0>, (const void *)pfac_scan_kernel<false, false, 1>},
-         {(const void *)pfac_scan_kernel<false, true, 0>, (const void *)pfac_scan_kernel<false, true, 1>}},
-        {{(const void *)pfac_scan_kernel<true, false, 0>, (const void *)pfac_scan_kernel<true, false, 1>},
-         {(const void *)pfac_scan_kernel<true, true, 0>, (const void *)pfac_scan_kernel<true, true, 1>}}};
-    ctx->kernel = k[ctx->variant == 0 ? 1 : 0][w8 ? 1 : 0][ctx->root_mode];
+    if (ctx->d_T4) { HIP_TRY(ctx, hipFree(ctx->d_T4)); ctx->d_T4 = nullptr; }
+    if (fused) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_T4, (size_t)ctx->ht_size * sizeof(int4)));
+        hipLaunchKernelGGL(pfac_fuse_kernel, dim3(256), dim3(256), 0, 0, ctx->d_T, ctx->d_r, ctx->width_bit, ctx->ht_size,
+                           ctx->max_row, ctx->d_T4);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipDeviceSynchronize());
+    }
+    const void *k[4][2][2] = {
+        {{(const void *)pfac_scan_kernel<false, false, 0, false, 2>, (const void *)pfac_scan_kernel<false, false, 1, false, 2>},
+         {(const void *)pfac_scan_kernel<false, true, 0, false, 2>, (const void *)pfac_scan_kernel<false, true, 1, false, 2>}},
+        {{(const void *)pfac_scan_kernel<true, false, 0, false, 1>, (const void *)pfac_scan_kernel<true, false, 1, false, 1>},
+         {(const void *)pfac_scan_kernel<true, true, 0, false, 1>, (const void *)pfac_scan_kernel<true, true, 1, false, 1>}},
+        {{(const void *)pfac_scan_kernel<false, false, 0, true, 2>, (const void *)pfac_scan_kernel<false, false, 1, true, 2>},
+         {(const void *)pfac_scan_kernel<false, true, 0, true, 2>, (const void *)pfac_scan_kernel<false, true, 1, true, 2>}},
+        {{(const void *)pfac_scan_kernel<false, false, 0, true, 4>, (const void *)pfac_scan_kernel<false, false, 1, true, 4>},
+         {(const void *)pfac_scan_kernel<false, true, 0, true, 4>, (const void *)pfac_scan_kernel<false, true, 1, true, 4>}}};
+    ctx->kernel = k[ctx->variant == 0 ? 1 : (fused ? 2 : 0)][w8 ? 1 : 0][ctx->root_mode];
+    // dense mode on fused L2 tables: four walks per lane (needs <= MAX_WAVES_NW4 waves per workgroup)
+    ctx->kernel_d = ctx->kernel;
+    if (fused && !getenv("PFAC_NO_NW4")) {
+        ctx->kernel_d = k[3][w8 ? 1 : 0][ctx->root_mode];
+        if (ctx->waves_per_block_d > MAX_WAVES_NW4) {
+            ctx->waves_per_block_d = MAX_WAVES_NW4;
+            ctx->lds_bytes_d = ctx->shared_bytes + (MAX_WAVES_NW4 - 1) * ctx->pw_bytes_d;
+            if (ctx->lds_bytes_d < LDS_TOTAL / 2 + 256) ctx->lds_bytes_d = LDS_TOTAL / 2 + 256;
+        }
+        HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel_d, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         ctx->lds_bytes > ctx->lds_bytes_d ? ctx->lds_bytes : ctx->lds_bytes_d));
+    }
     HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      ctx->lds_bytes > ctx->lds_bytes_d ? ctx->lds_bytes : ctx->lds_bytes_d));
     return PFAC_OK;
@@ -1228,6 +1399,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
     }
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_d1) (void)hipFree(ctx->d_d1);
+    if (ctx->d_T4) (void)hipFree(ctx->d_T4);
     delete ctx;
 }
 
@@ -1344,12 +1516,16 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         ScanArgs a;
         a.in = in; a.n_owned = n_owned; a.n_avail = n_avail;
         a.out = d_records; a.out_cap = capacity;
-        a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T;
+        a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T; a.T4 = ctx->d_T4;
         a.r_words = ctx->max_row; a.t_entries = ctx->ht_size;
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
         a.halo = ctx->halo;
         a.shared_bytes = ctx->shared_bytes; a.pw_bytes = dense ? ctx->pw_bytes_d : ctx->pw_bytes;
         a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows;
+        a.d1_n2 = ctx->d1_n2;
+        a.d1r2 = ctx->d1_n2 ? reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ctx->d_d1) +
+                                                            (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4)
+                            : nullptr;
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;
         a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
@@ -1368,7 +1544,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         const uint64_t want = n_batches;
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
         void *kargs[] = {&a};
-        HIP_TRY(ctx, hipLaunchKernel(ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
+        HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
     }
     HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
     return PFAC_OK;

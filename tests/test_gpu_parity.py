@@ -85,6 +85,21 @@ def test_gphf_cli_config1(resolve, tmp_path):
     assert (tmp_path / "GPU_match_result.txt").read_bytes() == exp.read_bytes()
 
 
+@pytest.mark.parametrize("width,env", [(256, {}), (1024, {}), (64, {}), (256, {"PFAC_NO_D1PACK": "1"}),
+                                       (4096, {"PFAC_NO_NW4": "1"}), (256, {"PFAC_NO_FUSE": "1"}), (256, {"PFAC_NO_D1": "1"})])
+def test_dictionary_dense_mode_kernels(width, env, resolve, monkeypatch):
+    """Dense staging mode on L2 tables: the fused-slot kernels with four walks per lane (width >= 256), the
+    unfused two-walk kernel (width 64) and every fallback knob -- all must give the oracle's records."""
+    monkeypatch.setenv("PFAC_DENSE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    table = PfacTable.from_file(resolve("xaa+xab+xac+xad"), width)
+    data = open(resolve("1M"), "rb").read()[:200001]
+    rec = gpu_records(table, data)
+    pos, ids = oracle_pairs(resolve("xaa+xab+xac+xad"), data)
+    assert_same(table, rec, pos, ids)
+
+
 @pytest.mark.parametrize("n_parts", [4, 7])
 def test_pattern_partition_mode_golden(n_parts, resolve, tmp_path):
     """Pattern-partition fallback (the reference's own scheme, ctr.c:217-247 + main.cc:304-324): every partition's
