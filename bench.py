@@ -36,11 +36,11 @@ GIB = 1 << 30
 
 WORKLOADS = {
     # name: (pattern fixture, input kind, description)
-    "text1g_experimentpattern": ("experimentpattern", "text", "experimentpattern (4 patterns) x reference 1M text tiled to 1 GiB/GPU"),
-    "text1g_bytefile10000": ("bytefile_10000byte", "text", "bytefile/10000byte (1376 patterns) x reference 1M text tiled to 1 GiB/GPU"),
-    "rand1g_experimentpattern": ("experimentpattern", "rand", "experimentpattern x splitmix64 random bytes, 1 GiB/GPU"),
-    "text1g_dictionary": ("xaa+xab+xac+xad", "text", "7989-word dictionary (xaa..xad) x reference 1M text tiled to 1 GiB/GPU"),
-    "text1g_snort75k": ("bytefile_1000000byte.gz", "text", "bytefile/1000000byte (75840 patterns, 542732 states, tables via L2) x reference 1M text tiled to 1 GiB/GPU"),
+    "text1g_experimentpattern": ("experimentpattern", "text", "experimentpattern (4 patterns) x reference 1M text tiled to {size}/GPU"),
+    "text1g_bytefile10000": ("bytefile_10000byte", "text", "bytefile/10000byte (1376 patterns) x reference 1M text tiled to {size}/GPU"),
+    "rand1g_experimentpattern": ("experimentpattern", "rand", "experimentpattern x splitmix64 random bytes, {size}/GPU"),
+    "text1g_dictionary": ("xaa+xab+xac+xad", "text", "7989-word dictionary (xaa..xad) x reference 1M text tiled to {size}/GPU"),
+    "text1g_snort75k": ("bytefile_1000000byte.gz", "text", "bytefile/1000000byte (75840 patterns, 542732 states, tables via L2) x reference 1M text tiled to {size}/GPU"),
 }
 
 
@@ -129,6 +129,7 @@ def main():
 
     def run_workload(name, steps, warmup):
         pat_name, kind, desc = WORKLOADS[name]
+        desc = desc.format(size=("%d GiB" % (per >> 30)) if per % GIB == 0 else ("%d bytes" % per))
         ppath = pattern_path(pat_name, tmpdir)
         g = GpuMatcher(local_rank, 2)          # two buffer sets (slots) ...
         g.set_stream(1, g.stream_handle(0))    # ... on ONE HIP stream: step k+1 is enqueued while step k runs
