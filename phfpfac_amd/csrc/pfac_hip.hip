@@ -109,6 +109,7 @@ struct ScanArgs {
     const int *d1r2;                      // FUSED + packed dense rows: r[] of the depth-2 states, d1_n2 words (else null)
     int d1_n2;                            // > 0: a dense-row entry is  state | index into d1r2 << 20  (or -1)
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
+    int root_state;                       // ROOT == 1: the state that byte leads to (every survivor starts there)
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
     unsigned nbuf;                        // staging buffers per wave: 3 = emit two rounds late, 1 = emit at once (dense mode)
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
@@ -316,8 +317,10 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 //    round trips and the wave has nothing else to do, so four chains per lane run side by side; the first
 //    MREG = 4 final states of a walk stay in registers (two otherwise) -- a position where more patterns start
 //    costs a second, serial walk (walk_store).
-template <bool W8, int NWALK, bool FUSED, int MREG>
-__device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, const unsigned char *d1idx,
+//  * ROOT == 1 (one byte leads out of the root): every survivor's first state is the same one and the dense row is
+//    row 0, so the root-row and row-index lookups -- two dependent LDS round trips per round -- disappear.
+template <bool W8, int NWALK, bool FUSED, int MREG, int ROOT>
+__device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, int root_state, const unsigned char *d1idx,
                                       const int *D1, bool dense1, const int *D1R2, const int *R, const int2 *T, const int4 *T4,
                                       const unsigned (&pos)[NWALK], const bool (&active)[NWALK], unsigned lim, int wbit,
                                       int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
@@ -334,8 +337,8 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     }
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
-        const int st = s0[win[w] & 0xFFu];
-        f[w] = d1idx[win[w] & 0xFFu];                          // dense row of that state (when dense1)
+        const int st = ROOT == 1 ? root_state : s0[win[w] & 0xFFu];
+        f[w] = ROOT == 1 ? 0u : d1idx[win[w] & 0xFFu];        // dense row of that state (when dense1)
         s[w] = active[w] ? st : -1;
         n[w] = 0;
 #pragma unroll
@@ -525,7 +528,7 @@ struct Dense1 {
 // One round: up to 64*NWALK survivors -- queue entries [q0, q0+nact), lane L takes entries L, L+64, ... walked
 // side by side -- append their records, in queue (= position) order, at index `wrun` of the staging
 // buffer (DIRECT == false) or of the global record array.  Returns the number of records.
-template <bool W8, bool DIRECT, int NWALK, bool FUSED>
+template <bool W8, bool DIRECT, int NWALK, bool FUSED, int ROOT>
 __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
                                            const int *R, const int2 *T, const unsigned short *q, unsigned q0,
                                            unsigned nact, int lane, unsigned *stage, unsigned lim,
@@ -539,8 +542,8 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
         active[w] = (unsigned)lane + WAVE * w < nact;
         pos[w] = active[w] ? q[q0 + WAVE * w + lane] : 0u;
     }
-    walkN<W8, NWALK, FUSED, MREG>(tile, s0, d1.idx, d1.rows, d1.on, d1.r2, R, T, a.T4, pos, active, lim, a.wbit, a.ht_size,
-                                  a.num_final, n, m);
+    walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, R, T, a.T4, pos, active, lim,
+                                        a.wbit, a.ht_size, a.num_final, n, m);
     // prefix sums of the counts, two walks per scan (16-bit fields; a walk reports < 1024 matches)
     unsigned ex[NWALK], total = 0;
 #pragma unroll
@@ -587,7 +590,7 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
 // in position order, to a FIFO in LDS; whenever 64 are pending a full round runs, so lanes stay
 // busy even when only one offset in thirteen survives the root test.  Returns the tile's match
 // count; with DIRECT the records are written at global index wrun onwards.
-template <bool W8, bool DIRECT, int NWALK, bool FUSED>
+template <bool W8, bool DIRECT, int NWALK, bool FUSED, int ROOT>
 __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
                                                         const Dense1 &d1, const int *R, const int2 *T, unsigned short *q,
                                                         unsigned *stage, const unsigned (&masks)[SUBS], int lane,
@@ -640,7 +643,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             constexpr unsigned RW = WAVE * NWALK;  // survivors per round
             unsigned h = 0;
             for (; h + RW <= tail; h += RW)
-                wrun += roundN<W8, DIRECT, NWALK, FUSED>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
+                wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
             if (h) {                               // move the < RW left-overs to the front
                 const unsigned rem = tail - h;
                 unsigned short v[NWALK];
@@ -654,7 +657,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             }
         }
     }
-    if (tail) wrun += roundN<W8, DIRECT, NWALK, FUSED>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun);
+    if (tail) wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun);
     return wrun;
 }
 
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * a.stage_cap;
-        const unsigned long long cnt = tile_pass<W8, false, NW, FUSED>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
+        const unsigned long long cnt = tile_pass<W8, false, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
         if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
         const bool overflow = cnt > a.stage_cap;
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
                 if (overflow)
                     // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
                     // while its bytes are still in LDS, writing straight to global memory
-                    tile_pass<W8, true, NW, FUSED>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
+                    tile_pass<W8, true, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
                 else
                     copy_out(a, stage, (unsigned)cnt, base, tile_base, lane);   // dense mode: staged, emitted at once
             }
@@ -1149,6 +1152,7 @@ struct pfac_ctx {
     const void *kernel_d = nullptr;       // the kernel dense mode launches (four walks per lane on fused L2 tables)
     int lds_bytes = 0, shared_bytes = 0, pw_bytes = 0, halo = 0, waves_per_block = 0, root_mode = 0;
     unsigned root_byte = 0, stage_cap = 0;
+    int root_state = -1;
     // the dense-mode twin of {pw_bytes, waves_per_block, lds_bytes, stage_cap}: one big staging buffer per wave
     int pw_bytes_d = 0, waves_per_block_d = 0, lds_bytes_d = 0;
     unsigned stage_cap_d = 0;
@@ -1259,6 +1263,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     // root fan-out 1 -> exact SWAR root test (ROOT = 1), else LDS flag tables (ROOT = 0)
     ctx->root_mode = fan == 1 ? 1 : 0;
     ctx->root_byte = (unsigned)rb * 0x01010101u;
+    ctx->root_state = s0_host[rb];
     ctx->stage_cap = ctx->num_final <= (1 << PACK_STATE_BITS) ? (unsigned)CAPW : 0u;
     // dense-mode layout
     ctx->pw_bytes_d = (int)align_up((size_t)PW_FIXED_DENSE + ctx->halo, 16);
@@ -1528,6 +1533,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
                             : nullptr;
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;
+        a.root_state = ctx->root_state;
         a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
         a.nbuf = dense ? 1u : (unsigned)NBUF;
         a.sparse_cap = ctx->stage_cap;
