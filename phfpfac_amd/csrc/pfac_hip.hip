@@ -23,7 +23,8 @@
  *            64 (x NWALK) survivors runs whenever that many are pending, so lanes stay dense
  *   walk     straight-line, predicated: root row and the dense depth-1 rows from LDS, deeper states
  *            through the perfect hash  state = PHF(state, byte)  from LDS (small tables) or L2
- *            (large); final states are recorded as they are met                     (mk.cu:49-71)
+ *            (large: 2-4 walks per lane, slots fused with the next state's r[] so a step is one
+ *            gather); final states are recorded as they are met                     (mk.cu:49-71)
  *   stage    records (pos:12 | state:20) go to an LDS staging buffer in (position, length) order
  *   order    per-wave counts -> coordinator -> batch aggregate -> decoupled look-back over batches
  *            (8-byte {flag,value} words, relaxed agent-scope atomics), pipelined over three rounds;
