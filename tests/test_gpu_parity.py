@@ -310,6 +310,55 @@ def test_full_size_properties(resolve):
         assert nm == opos.size and g.checksum(nm) == match_checksum(opos, oids)
 
 
+def test_maximum_shard_4gib_positions_past_2_31(resolve, tmp_path):
+    """The largest shard one scan takes: n_owned = 2^32 (C4/C5 shard size).  Record positions are unsigned 32-bit
+    and must be exact past 2^31 and up to 2^32 - 1; count from the input's period, tail records against the oracle
+    on the last bytes of the stream, text of those records, checksum linearity over two 2 GiB halves."""
+    import torch
+    para = open(resolve("paragraph402"), "rb").read()
+    N = 1 << 32
+    pat = resolve("experimentpattern")
+    table = PfacTable.from_file(pat, 256)
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        buf = torch.empty(N + 1024, dtype=torch.uint8, device="cuda:0")
+        g.fill_tiled(buf, N, para)
+        g.reserve(0, 0, 340_000_000)
+        n = g.scan_resident(N, N, d_input=buf)
+        win = tiled_bytes(402 * 8, para)
+        pos, _ = oracle_pairs(pat, win)
+        per_period = int(((pos >= 402) & (pos < 804)).sum())
+        full, tail = divmod(N, 402)
+        assert tail >= 3
+        lpos, _ = oracle_pairs(pat, tiled_bytes(tail, para))
+        assert n == per_period * full + lpos.size
+        total_sum = g.checksum(n)
+        # the last records: oracle over the last W bytes of the stream (same end of input, so the same cut-offs)
+        W = 6000
+        wdata = tiled_bytes(W, para, phase=(N - W) % 402)
+        opos, oids = oracle_pairs(pat, wdata)
+        assert opos.size > 100
+        rec = g.records_to_host(opos.size, first=n - opos.size)
+        np.testing.assert_array_equal(rec["pos"].astype(np.int64), opos + (N - W))
+        np.testing.assert_array_equal(table.idmap[rec["state"]], oids)
+        assert int(rec["pos"][0]) > (1 << 31) and int(rec["pos"][-1]) >= N - 402
+        out = tmp_path / "tail.txt"
+        emit_records(str(out), rec, table.idmap)
+        want = "".join("At position %4d, match pattern %d\n" % (p + N - W, i) for p, i in zip(opos, oids))
+        assert out.read_text() == want
+        # sortedness around the 2^31 boundary
+        k = int(n // 2)
+        mid = g.records_to_host(1 << 16, first=k - (1 << 15))
+        assert (np.diff(mid["pos"].astype(np.int64)) > -1).all()
+        # linearity: two 2 GiB halves (second with base 2^31)
+        half = N // 2
+        n0 = g.scan_resident(half, half + table.halo, d_input=buf)
+        s0 = g.checksum(n0, base=0)
+        n1 = g.scan_resident(half, half, d_input=int(buf.data_ptr()) + half)
+        s1 = g.checksum(n1, base=half)
+        assert n0 + n1 == n and (s0 + s1) % (1 << 64) == total_sum
+
+
 def test_random_fill_matches_cpu_twin_and_oracle(resolve):
     import torch
     n = 1 << 22
