@@ -410,6 +410,26 @@ def test_errors_are_loud(resolve):
             g.scan_async(16)                                   # scan before a table upload
     with pytest.raises(PfacError):
         GpuMatcher(99, 1)                                      # no such device
+    import torch
+    table = PfacTable.from_file(resolve("experimentpattern"), 256)
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        buf = torch.zeros(4096 + 64, dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(PfacError):
+            g.scan_async((1 << 32) + 1, (1 << 32) + 1, d_input=buf)     # more than one scan's 2^32 positions
+        with pytest.raises(PfacError):
+            g.scan_async(100, 50, d_input=buf)                 # n_owned > n_avail
+        with pytest.raises(PfacError):
+            g.scan_async(64, 64, d_input=int(buf.data_ptr()) + 4)       # input not 16-byte aligned
+        with pytest.raises(PfacError):
+            g.scan_finish(0)                                   # nothing was scanned
+        # a record buffer that is too small: the count is still exact, the caller learns it has to grow
+        buf[:4096] = torch.from_numpy(tiled_bytes(4096, open(resolve("paragraph402"), "rb").read()).copy()).to("cuda:0")
+        g.reserve(0, 0, 16)
+        g.scan_async(4096, 4096, d_input=buf)
+        n, over = g.scan_finish(0, allow_overflow=True)
+        pos, _ = oracle_pairs(resolve("experimentpattern"), tiled_bytes(4096, open(resolve("paragraph402"), "rb").read()))
+        assert over and n == pos.size > 16
 
 
 def test_rccl_path_single_rank(resolve):
