@@ -40,6 +40,7 @@ WORKLOADS = {
     "text1g_bytefile10000": ("bytefile_10000byte", "text", "bytefile/10000byte (1376 patterns) x reference 1M text tiled to {size}/GPU"),
     "rand1g_experimentpattern": ("experimentpattern", "rand", "experimentpattern x splitmix64 random bytes, {size}/GPU"),
     "text1g_dictionary": ("xaa+xab+xac+xad", "text", "7989-word dictionary (xaa..xad) x reference 1M text tiled to {size}/GPU"),
+    "rand1g_snort75k": ("bytefile_1000000byte.gz", "rand", "bytefile/1000000byte (75840 patterns, 542732 states, tables via L2) x splitmix64 random bytes, {size}/GPU"),
     "text1g_snort75k": ("bytefile_1000000byte.gz", "text", "bytefile/1000000byte (75840 patterns, 542732 states, tables via L2) x reference 1M text tiled to {size}/GPU"),
 }
 

@@ -322,7 +322,7 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 //    row 0, so the root-row and row-index lookups -- two dependent LDS round trips per round -- disappear.
 template <bool W8, int NWALK, bool FUSED, int MREG, int ROOT>
 __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, int root_state, const unsigned char *d1idx,
-                                      const int *D1, bool dense1, const int *D1R2, const int *R, const int2 *T, const int4 *T4,
+                                      const int *D1, bool dense1, const int *D1R2, const int *S0R, const int *R, const int2 *T, const int4 *T4,
                                       const unsigned (&pos)[NWALK], const bool (&active)[NWALK], unsigned lim, int wbit,
                                       int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
     static_assert(MREG == 2 || MREG == 4, "two or four final states per walk in registers");
@@ -459,7 +459,14 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             p[w]++;
         }
     } else {
-        load_rn();
+        if (FUSED && S0R) {
+            // too many depth-1 states for dense rows: their r[] at least sits in LDS (by root byte), so the second
+            // byte costs one gather, not two
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) rn[w] = S0R[win[w] & 0xFFu];
+        } else {
+            load_rn();
+        }
         step(1);
     }
     if (!reached()) return;
@@ -524,6 +531,7 @@ struct Dense1 {
     const int *rows;
     bool on;
     const int *r2;      // packed rows (FUSED): r[] of the depth-2 states, in LDS; null = plain rows
+    const int *s0r;     // no dense rows (FUSED): r[] of the depth-1 state each root byte leads to, in LDS; else null
 };
 
 // One round: up to 64*NWALK survivors -- queue entries [q0, q0+nact), lane L takes entries L, L+64, ... walked
@@ -543,7 +551,7 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
         active[w] = (unsigned)lane + WAVE * w < nact;
         pos[w] = active[w] ? q[q0 + WAVE * w + lane] : 0u;
     }
-    walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, R, T, a.T4, pos, active, lim,
+    walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, lim,
                                         a.wbit, a.ht_size, a.num_final, n, m);
     // prefix sums of the counts, two walks per scan (16-bit fields; a walk reports < 1024 matches)
     unsigned ex[NWALK], total = 0;
@@ -759,7 +767,15 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     int *d1r2_l = reinterpret_cast<int *>(smem + SH_D1 + a.d1_rows * 1024);
     if (FUSED && a.d1_n2 > 0)
         for (int i = tid; i < a.d1_n2; i += blockDim.x) d1r2_l[i] = a.d1r2[i];
-    const Dense1 d1 = {d1idx_l, d1_l, a.d1_rows > 0, (FUSED && a.d1_n2 > 0) ? d1r2_l : nullptr};
+    // FUSED without dense rows: r[] of the depth-1 states by root byte, in the (unused) dense-row region
+    int *s0r_l = reinterpret_cast<int *>(smem + SH_D1);
+    const bool have_s0r = FUSED && a.d1_rows == 0;
+    if (have_s0r)
+        for (int i = tid; i < 256; i += blockDim.x) {
+            const int v = a.s0[i];
+            s0r_l[i] = v >= 0 ? a.r[v >> (a.wbit - 8)] : 0;
+        }
+    const Dense1 d1 = {d1idx_l, d1_l, a.d1_rows > 0, (FUSED && a.d1_n2 > 0) ? d1r2_l : nullptr, have_s0r ? s0r_l : nullptr};
     const int sh_tab = SH_D1 + a.d1_rows * 1024;     // (the packed rows' r[] and LDS tables never coexist)
     const int *R = a.r;
     const int2 *T = a.T;
@@ -1251,6 +1267,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         }
     }
     ctx->shared_bytes = SH_D1 + ctx->d1_rows * 1024 + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 4, 16));
+    if (fused && ctx->d1_rows == 0) ctx->shared_bytes += 1024;   // r[] of the depth-1 states by root byte
     ctx->pw_bytes = (int)align_up((size_t)PW_FIXED + ctx->halo, 16);
     int nwb = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes + 1;     // compute waves + the coordinator (no LDS region)
     if (nwb > MAX_WAVES_PER_BLOCK) nwb = MAX_WAVES_PER_BLOCK;
