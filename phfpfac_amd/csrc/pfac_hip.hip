@@ -744,7 +744,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     unsigned char *ftab = smem + SH_FTAB;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int nc = (int)(blockDim.x >> 6) - 1;             // compute waves; wave nc coordinates
     unsigned *err = &a.res[2];             // error paths only: an atomic on host memory is fine there
 
@@ -902,13 +902,18 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     // first record index of this wave's tile of round rr (computed by the coordinator)
     auto record_base = [&](unsigned rr, unsigned long long &base) -> bool {
         if (!lds_wait_eq(&hdr[H_READY + (rr & 7)], rr + 1, err, 8u)) return false;
-        base = ((unsigned long long)hdr[H_WBASE + (rr & 7) * 32 + wave * 2 + 1] << 32) | hdr[H_WBASE + (rr & 7) * 32 + wave * 2];
+        // (every lane reads the same words: tell the compiler, so the record addresses get a scalar base)
+        const unsigned blo = __builtin_amdgcn_readfirstlane(hdr[H_WBASE + (rr & 7) * 32 + wave * 2]);
+        const unsigned bhi = __builtin_amdgcn_readfirstlane(hdr[H_WBASE + (rr & 7) * 32 + wave * 2 + 1]);
+        base = ((unsigned long long)bhi << 32) | blo;
         return true;
     };
 
     unsigned r = 0;
     if (!lds_wait_eq(&hdr[H_EPOCH], 1u, err, 16u)) return;
-    unsigned long long t = (unsigned long long)hdr[H_BATCH] * (unsigned)nc + (unsigned)wave;
+    // tile numbers are wave-uniform: as scalars they make the buffer descriptor of the tile loads a scalar too
+    // (a descriptor in VGPRs costs a readfirstlane "waterfall" loop around every load)
+    unsigned long long t = (unsigned long long)__builtin_amdgcn_readfirstlane(hdr[H_BATCH]) * (unsigned)nc + (unsigned)wave;
     if (t >= a.n_tiles) return;
     issue_loads(t);
 
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         bool more = lds_wait_eq(&hdr[H_EPOCH + ((r + 1) & 7)], r + 2, err, 16u);
         unsigned long long t_next = 0;
         if (more) {
-            t_next = (unsigned long long)hdr[H_BATCH + ((r + 1) & 7)] * (unsigned)nc + (unsigned)wave;
+            t_next = (unsigned long long)__builtin_amdgcn_readfirstlane(hdr[H_BATCH + ((r + 1) & 7)]) * (unsigned)nc + (unsigned)wave;
             more = t_next < a.n_tiles;
         }
         if (more) issue_loads(t_next);
