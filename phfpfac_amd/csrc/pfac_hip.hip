@@ -17,8 +17,8 @@
  *   stage    each wave loads its 4 KiB with 16-B-per-lane buffer loads (hardware bounds check ->
  *            bytes past n_avail read as 0), one round ahead, and mirrors them + the max_pat_len-1
  *            halo into its private LDS region
- *   root     16-bit "has a root edge" mask per lane per 16 bytes: SWAR compare + v_dot4 when the root
- *            has a single edge, else one LDS flag lookup per byte                    (mk.cu:41)
+ *   root     32-bit "has a root edge" mask per lane per 32 contiguous bytes (two halves per tile): SWAR
+ *            compare + v_dot4 when the root has a single edge, else one LDS flag lookup per byte (mk.cu:41)
  *   compact  DPP prefix sums append the survivors' positions, in order, to a FIFO in LDS; a round of
  *            64 (x NWALK) survivors runs whenever that many are pending, so lanes stay dense
  *   walk     straight-line, predicated: root row and the dense depth-1 rows from LDS, deeper states
@@ -56,6 +56,9 @@ constexpr int WAVE = 64;
 constexpr int SUB = WAVE * 16;             // bytes one wave covers with one 16-B-per-lane load (1 KiB)
 constexpr int SUBS = 4;                    // such sub-tiles per wave tile
 constexpr int WTILE = SUB * SUBS;          // 4096: tile-local positions fit 12 bits
+constexpr int MSUBS = 2;                   // root test / compaction: the tile as 2 halves, a lane owning 32 contiguous bytes of each
+constexpr int MSUB = WTILE / MSUBS;        // 2048
+constexpr int MLANE = MSUB / WAVE;         // 32 bytes per lane -> one 32-bit survivor mask
 constexpr int HALO_MAX = 1024;             // >= max_pat_len - 1 (patterns are < 1024 bytes), multiple of 16
 constexpr int QCAP = SUB / 2 + 4 * WAVE;   // survivor FIFO: < one round (at most 4 x 64) carried over + up to 512 appended at a time
 #ifndef PFAC_CAPW
@@ -602,54 +605,45 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
 template <bool W8, bool DIRECT, int NWALK, bool FUSED, int ROOT>
 __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
                                                         const Dense1 &d1, const int *R, const int2 *T, unsigned short *q,
-                                                        unsigned *stage, const unsigned (&masks)[SUBS], int lane,
+                                                        unsigned *stage, const unsigned (&masks)[MSUBS], int lane,
                                                         unsigned lim, unsigned long long tile_base,
                                                         unsigned long long wrun) {
-    unsigned tail = 0;                         // pending survivors, always < one round between sub-tiles
-    // per-lane survivor counts of the 4 sub-tiles, prefix-summed two at a time (16-bit fields: a
-    // sub-tile holds at most 1024 survivors); the two independent DPP chains fill each other's wait states
-    static_assert(SUBS == 4, "packed scans assume 4 sub-tiles");
-    const unsigned c0 = __popc(masks[0]), c1 = __popc(masks[1]), c2 = __popc(masks[2]), c3 = __popc(masks[3]);
-    unsigned pa = c0 | (c1 << 16), pb = c2 | (c3 << 16);
-    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x111, 0xf, 0xf, false);
-    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x111, 0xf, 0xf, false);
-    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x112, 0xf, 0xf, false);
-    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x112, 0xf, 0xf, false);
-    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x114, 0xf, 0xf, false);
-    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x114, 0xf, 0xf, false);
-    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x118, 0xf, 0xf, false);
-    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x118, 0xf, 0xf, false);
-    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x142, 0xa, 0xf, false);
-    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x142, 0xa, 0xf, false);
-    pa += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pa, 0x143, 0xc, 0xf, false);
-    pb += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pb, 0x143, 0xc, 0xf, false);
-    const unsigned incls[SUBS] = {pa & 0xFFFFu, pa >> 16, pb & 0xFFFFu, pb >> 16};
-    const unsigned cnts[SUBS] = {c0, c1, c2, c3};
-    const unsigned la = bcast_last(pa), lb = bcast_last(pb);
-    const unsigned totals[SUBS] = {la & 0xFFFFu, la >> 16, lb & 0xFFFFu, lb >> 16};
+    unsigned tail = 0;                         // pending survivors, always < one round between appends
+    // per-lane survivor counts of the 2 half-tiles, prefix-summed in one packed DPP scan (16-bit fields: a
+    // half-tile holds at most 2048 survivors)
+    static_assert(MSUBS == 2, "the packed scan assumes 2 half-tiles");
+    const unsigned c0 = __popc(masks[0]), c1 = __popc(masks[1]);
+    const unsigned pa = wave_incl_scan(c0 | (c1 << 16));
+    const unsigned incls[MSUBS] = {pa & 0xFFFFu, pa >> 16};
+    const unsigned cnts[MSUBS] = {c0, c1};
+    const unsigned la = bcast_last(pa);
+    const unsigned totals[MSUBS] = {la & 0xFFFFu, la >> 16};
+    constexpr unsigned RW = WAVE * NWALK;      // survivors per round
 #pragma unroll
-    for (int j = 0; j < SUBS; j++) {
+    for (int j = 0; j < MSUBS; j++) {
         const unsigned mask = masks[j];
         const unsigned cnt = cnts[j];
         const unsigned incl = incls[j];
         const unsigned S = totals[j];
         if (S == 0) continue;
-        const unsigned lpos = j * SUB + lane * 16;
-        // A sub-tile with more than 512 survivors is appended in two lane halves (lanes 0-31 hold at most
-        // 32 * 16 = 512 of them, and come first in position order), so the FIFO needs 512 + 128 slots only.
-        const unsigned S_lo = __builtin_amdgcn_readlane(incl, 31);
-        const int nhalf = S > (unsigned)(SUB / 2) ? 2 : 1;
-        for (int hf = 0; hf < nhalf; hf++) {
-            const bool mine = nhalf == 1 || (lane >> 5) == hf;
-            const unsigned hbase = hf == 1 ? S_lo : 0u;
-            const unsigned hcnt = nhalf == 1 ? S : (hf == 0 ? S_lo : S - S_lo);
+        const unsigned lpos = j * MSUB + lane * MLANE;
+        // A half-tile with more than 512 survivors is appended in four groups of 16 lanes (16 * 32 = 512 positions,
+        // in position order), so the FIFO needs one round's left-overs + 512 slots only.
+        const int ngrp = S > 512u ? 4 : 1;
+        for (int gi = 0; gi < ngrp; gi++) {
+            unsigned gbase = 0, gcnt = S;
+            bool mine = true;
+            if (ngrp != 1) {
+                gbase = gi ? __builtin_amdgcn_readlane(incl, 16 * gi - 1) : 0u;
+                gcnt = __builtin_amdgcn_readlane(incl, 16 * gi + 15) - gbase;
+                mine = (lane >> 4) == gi;
+            }
             if (mine) {
-                unsigned o = tail + (incl - cnt) - hbase;
+                unsigned o = tail + (incl - cnt) - gbase;
                 for (unsigned m = mask; m; m &= m - 1) q[o++] = (unsigned short)(lpos + (__ffs(m) - 1));
             }
-            tail += hcnt;
+            tail += gcnt;
             wave_lds_sync();
-            constexpr unsigned RW = WAVE * NWALK;  // survivors per round
             unsigned h = 0;
             for (; h + RW <= tail; h += RW)
                 wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
@@ -949,18 +943,19 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         if (more) issue_loads(t_next);
 
         // ---- root test -> 16-bit survivor mask per lane per sub-tile
-        unsigned masks[SUBS];
+        unsigned masks[MSUBS];
 #pragma unroll
-        for (int j = 0; j < SUBS; j++) {
-            const unsigned off = j * SUB + lane * 16;
-            const u32x4 ww = *reinterpret_cast<const u32x4 *>(tile + off);
-            masks[j] = root_mask<ROOT>(ww, ftab, a.root_byte);
+        for (int j = 0; j < MSUBS; j++) {
+            const unsigned off = j * MSUB + lane * MLANE;
+            const u32x4 lo16 = *reinterpret_cast<const u32x4 *>(tile + off);
+            const u32x4 hi16 = *reinterpret_cast<const u32x4 *>(tile + off + 16);
+            masks[j] = root_mask<ROOT>(lo16, ftab, a.root_byte) | (root_mask<ROOT>(hi16, ftab, a.root_byte) << 16);
         }
         if (tile_base + WTILE > a.n_owned) {   // last tile only: offsets at or past n_owned start no walk
 #pragma unroll
-            for (int j = 0; j < SUBS; j++) {
-                const unsigned long long g = tile_base + j * SUB + lane * 16;
-                if (g + 16 > a.n_owned) masks[j] = g >= a.n_owned ? 0u : (masks[j] & ((1u << (unsigned)(a.n_owned - g)) - 1u));
+            for (int j = 0; j < MSUBS; j++) {
+                const unsigned long long g = tile_base + j * MSUB + lane * MLANE;
+                if (g + MLANE > a.n_owned) masks[j] = g >= a.n_owned ? 0u : (masks[j] & ((1u << (unsigned)(a.n_owned - g)) - 1u));
             }
         }
 
