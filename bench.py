@@ -61,6 +61,38 @@ def pattern_path(name, tmpdir):
     return p
 
 
+def cpu_baseline_threads(pat_path, kind, para, n_threads, seconds=8.0):
+    """The same serial Aho-Corasick scan on n_threads host threads, each over its own 32 MiB slice (plus halo) of
+    the workload, repeated for a few seconds -- the all-cores figure next to the one-core baseline."""
+    import threading
+    from orc import Oracle, lib
+    from phfpfac_amd.matcher import splitmix64_bytes, tiled_bytes
+    import ctypes as C
+    L = lib()
+    o = Oracle(pat_path, 1, 1)
+    ac = L.ac_build(o.m)
+    piece = 32 << 20
+    buf = tiled_bytes(piece + 1024, para) if kind == "text" else splitmix64_bytes(piece + 1024, 0x5048465046414331)
+    done = [0] * n_threads
+    stop = time.perf_counter() + seconds
+
+    def work(i):
+        chk = C.c_uint64(0)
+        while time.perf_counter() < stop:
+            L.ac_scan_count(ac, buf.ctypes.data, piece, C.byref(chk))      # ctypes releases the GIL during the call
+            done[i] += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    L.ac_free(ac)
+    o.close()
+    return {"value": round(sum(done) * piece / dt / 1e9, 3), "unit": "GB/s", "cores": n_threads, "kind": "port",
+            "sample": f"{sum(done)} scans of a 32 MiB slice on {n_threads} threads ({dt:.1f} s), serial Aho-Corasick full-DFA per thread"}
+
+
 def cpu_baseline(pat_path, kind, para, seconds=12.0):
     """Serial Aho-Corasick on ONE host core over a bounded sample of the same workload."""
     from orc import Oracle, lib
@@ -97,6 +129,7 @@ def main():
     ap.add_argument("--bytes-per-gpu", type=int, default=GIB)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also time the other workloads (short) and report them")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="also report the CPU baseline on this many host threads")
     args = ap.parse_args()
 
     import torch
@@ -276,6 +309,8 @@ def main():
                 "matches_per_step": r["matches"], "kernel_variant": r["info"]["variant"]}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(res["ppath"], res["kind"], para)
+        if args.cpu_threads > 1:
+            out["cpu_baseline_threads"] = cpu_baseline_threads(res["ppath"], res["kind"], para, args.cpu_threads)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
