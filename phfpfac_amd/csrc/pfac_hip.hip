@@ -119,6 +119,8 @@ struct ScanArgs {
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
     unsigned n_tiles;
     unsigned *ctl;                 // [0] batch ticket (device memory)
+    uint4 *zero_next;              // the slot's OTHER control buffer: this launch zeroes it for the next one ...
+    unsigned zero_vec;             // ... this many 16-byte units (no memset between back-to-back scans)
     unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy:
                                    // [0..1] total matches (u64), [2] error flags, [3] tiles denser than sparse_cap
     unsigned long long *status;    // one look-back word per batch
@@ -742,6 +744,10 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     const int nc = (int)(blockDim.x >> 6) - 1;             // compute waves; wave nc coordinates
     unsigned *err = &a.res[2];             // error paths only: an atomic on host memory is fine there
 
+    // ---- the control words of the slot's NEXT scan (ticket + look-back words of its other buffer) are zeroed here,
+    // spread over the whole grid: the next launch on the stream starts after this one has ended
+    for (unsigned i = blockIdx.x * blockDim.x + tid; i < a.zero_vec; i += gridDim.x * blockDim.x)
+        a.zero_next[i] = make_uint4(0u, 0u, 0u, 0u);
     // ---- once per workgroup: rings cleared, root row, root flag tables, (small) PHF tables -> LDS
     for (int i = tid; i < H_WORDS; i += blockDim.x) hdr[i] = 0;
     for (int i = tid; i < 256; i += blockDim.x) {
@@ -1139,8 +1145,11 @@ struct Slot {
     uint64_t input_cap = 0;
     pfac_record *d_records = nullptr;
     uint64_t record_cap = 0;
-    unsigned *d_ctl = nullptr;            // 16 control words followed by the status array
-    uint64_t status_cap = 0;              // tiles
+    unsigned *d_ctl = nullptr;            // TWO control buffers (16 control words + the status array each), used alternately:
+    unsigned *d_ctlbuf[2] = {nullptr, nullptr};   // a scan zeroes the other one for the scan after it
+    uint64_t clean[2] = {0, 0};           // status words (from 0) of each buffer known to be zero
+    int flip = 0;                         // buffer of the next scan
+    uint64_t status_cap = 0;              // status words per buffer
     unsigned *h_ctl = nullptr;            // pinned, device-visible: [0..1] total, [2] err (written by the kernel), [4..5] checksum
     unsigned *d_res = nullptr;            // device-side address of h_ctl
     unsigned long long *d_sum = nullptr;
@@ -1206,12 +1215,21 @@ int check_slot(pfac_ctx *ctx, int slot) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int ensure_status(pfac_ctx *ctx, Slot &s, uint64_t n_tiles) {
-    if (s.d_ctl && s.status_cap >= n_tiles) return PFAC_OK;
-    if (s.d_ctl) HIP_TRY(ctx, hipFree(s.d_ctl));
+int ensure_status(pfac_ctx *ctx, Slot &s, uint64_t n_words) {
+    if (s.d_ctl && s.status_cap >= n_words) return PFAC_OK;
+    if (s.d_ctl) {
+        HIP_TRY(ctx, hipStreamSynchronize(s.stream));            // a running scan may still be zeroing the old buffers
+        HIP_TRY(ctx, hipFree(s.d_ctl));
+    }
     s.d_ctl = nullptr;
-    uint64_t cap = n_tiles < 4096 ? 4096 : n_tiles;
-    HIP_TRY(ctx, hipMalloc((void **)&s.d_ctl, 64 + cap * 8 + 16));
+    uint64_t cap = n_words < 4096 ? 4096 : n_words + n_words / 4;
+    const size_t region = align_up(64 + cap * 8 + 16, 256);
+    HIP_TRY(ctx, hipMalloc((void **)&s.d_ctl, 2 * region));
+    HIP_TRY(ctx, hipMemset(s.d_ctl, 0, 2 * region));
+    s.d_ctlbuf[0] = s.d_ctl;
+    s.d_ctlbuf[1] = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(s.d_ctl) + region);
+    s.clean[0] = s.clean[1] = cap;
+    s.flip = 0;
     s.status_cap = cap;
     return PFAC_OK;
 }
@@ -1485,7 +1503,9 @@ int pfac_slot_set_stream(pfac_ctx *ctx, int slot, void *stream_handle) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
-    s.stream = stream_handle ? reinterpret_cast<hipStream_t>(stream_handle) : s.own_stream;
+    hipStream_t ns = stream_handle ? reinterpret_cast<hipStream_t>(stream_handle) : s.own_stream;
+    if (ns != s.stream && s.pending) HIP_TRY(ctx, hipStreamSynchronize(s.stream));   // a scan in flight zeroes the next scan's control words
+    s.stream = ns;
     return PFAC_OK;
 }
 
@@ -1520,8 +1540,6 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     s.scanned = true;
     s.pending = true;
     s.h_ctl[0] = s.h_ctl[1] = s.h_ctl[2] = 0;          // result words (the kernel writes them through the host mapping)
-    rc = ensure_status(ctx, s, n_tiles);
-    if (rc) return rc;
     // staging mode of this launch (see pfac_scan_finish for the adaptation)
     const bool dense = ctx->dense && ctx->stage_cap_d;
     const int wpb = dense ? ctx->waves_per_block_d : ctx->waves_per_block;
@@ -1529,11 +1547,16 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     s.last_dense = dense;
     s.last_tiles = n_tiles;
     s.h_ctl[3] = 0;
-    // ticket + one look-back word per batch (+ the tickets taken ahead by every workgroup), zeroed every call
+    // ticket + one look-back word per batch (+ the tickets taken ahead by every workgroup) must start at zero.  The
+    // slot has two control buffers: every scan zeroes, in its own prologue, what the next scan needs in the other
+    // one, so back-to-back scans of similar size need no memset; anything else falls back to one.
     const uint64_t n_batches = (n_tiles + wpb - 2) / (wpb - 1);
-    uint64_t zero_words = n_batches + 4ull * ctx->grid_blocks + 8;
-    if (zero_words > s.status_cap) zero_words = s.status_cap;
-    HIP_TRY(ctx, hipMemsetAsync(s.d_ctl, 0, 64 + align_up(zero_words * 8, 16), s.stream));
+    const uint64_t need = n_batches + 6ull * ctx->grid_blocks + 8;
+    rc = ensure_status(ctx, s, need);
+    if (rc) return rc;
+    unsigned *const cur = s.d_ctlbuf[s.flip], *const nxt = s.d_ctlbuf[1 - s.flip];
+    if (n_tiles > 0 && s.clean[s.flip] < need)
+        HIP_TRY(ctx, hipMemsetAsync(cur, 0, 64 + align_up(need * 8, 16), s.stream));
     HIP_TRY(ctx, hipEventRecord(s.ev0, s.stream));
     if (n_tiles > 0) {
         ScanArgs a;
@@ -1556,9 +1579,11 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.nbuf = dense ? 1u : (unsigned)NBUF;
         a.sparse_cap = ctx->stage_cap;
         a.n_tiles = (unsigned)n_tiles;
-        a.ctl = s.d_ctl;
+        a.ctl = cur;
+        a.zero_next = reinterpret_cast<uint4 *>(nxt);
+        a.zero_vec = (unsigned)((64 + align_up(need * 8, 16)) / 16);
         a.res = s.d_res;
-        a.status = reinterpret_cast<unsigned long long *>(s.d_ctl + 16);
+        a.status = reinterpret_cast<unsigned long long *>(cur + 16);
         a.dbg = nullptr;
         if (getenv("PFAC_TRACE")) {
             if (!s.d_dbg) HIP_TRY(ctx, hipMalloc((void **)&s.d_dbg, 8 * 64 * 32 * 8));
@@ -1569,6 +1594,9 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
         void *kargs[] = {&a};
         HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
+        s.clean[s.flip] = 0;                   // used by this scan
+        s.clean[1 - s.flip] = need;            // zeroed by this scan
+        s.flip = 1 - s.flip;
     }
     HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
     return PFAC_OK;
@@ -1590,7 +1618,10 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
             if (FILE *f = fopen(getenv("PFAC_TRACE"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         }
     }
-    if (s.h_ctl[2] != 0) return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a look-back timeout");
+    if (s.h_ctl[2] != 0) {
+        s.clean[0] = s.clean[1] = 0;           // whatever state the control buffers are in: zero them before the next scan
+        return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a look-back timeout");
+    }
     // Staging mode for the NEXT scans of this context: when more than a quarter of the tiles held more matches
     // than the small (three-buffer) staging area takes, go dense (one big buffer, emitted at once, no second
     // walk); go back when fewer than 1/16 do.  PFAC_DENSE=0/1 pins the mode.
