@@ -5,7 +5,8 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path over one batch of synthetic input that is ALREADY RESIDENT in
-HBM: zero the control/look-back words, run the scan kernel over this rank's shard (1 GiB owned +
+HBM: run the scan kernel over this rank's shard (its control/look-back words were zeroed by the slot's previous
+scan; 1 GiB owned +
 max_pat_len-1 bytes of halo) and read back the exact match count; with N > 1 the per-rank counts of the K steps
 are all-gathered once, inside the timed region (the one exchange the sharded path needs, to place records).  Weak scaling: every rank owns
 1 GiB, so the global stream is N GiB.  The workload is BASELINE.json configs[1]: pattern file
