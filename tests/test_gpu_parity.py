@@ -359,6 +359,56 @@ def test_maximum_shard_4gib_positions_past_2_31(resolve, tmp_path):
         assert n0 + n1 == n and (s0 + s1) % (1 << 64) == total_sum
 
 
+def test_back_to_back_scans_of_varied_sizes(resolve):
+    """Hundreds of scans of random lengths / offsets on two pipeline slots sharing a stream, counts checked against
+    the oracle's per-phase match table of the periodic text: the control words of a scan are zeroed by the slot's
+    previous scan (or by a fallback memset when the size jumps), and a stale word would derail the look-back."""
+    import torch
+    para = open(resolve("paragraph402"), "rb").read()
+    pat = resolve("experimentpattern")
+    table = PfacTable.from_file(pat, 256)
+    o = Oracle(pat, 1, 1)
+    pos, _ = o.scan_spec(tiled_bytes(402 * 4, para))
+    per_phase = np.bincount(pos[(pos >= 402) & (pos < 804)] - 402, minlength=402)
+    cum = np.concatenate([[0], np.cumsum(per_phase)])
+
+    def expected(start, n_owned, n_avail):
+        full, rem = divmod(n_owned, 402)
+        idx = (start % 402 + np.arange(rem)) % 402
+        cnt = int(full * cum[402] + per_phase[idx].sum())
+        k = min(n_owned, 8)                                   # the last offsets may lose matches to the end of the range
+        tail_lo = start + n_owned - k
+        tp, _ = o.scan_spec(tiled_bytes(start + n_avail - tail_lo, para, phase=tail_lo % 402))
+        return cnt - int(per_phase[(tail_lo % 402 + np.arange(k)) % 402].sum()) + int((tp < k).sum())
+
+    N = 1 << 28
+    rng = np.random.default_rng(11)
+    buf = torch.empty(N + 4096, dtype=torch.uint8, device="cuda:0")
+    with GpuMatcher(0, 2) as g:
+        g.set_stream(1, g.stream_handle(0))
+        g.load_table(table)
+        g.fill_tiled(buf, N, para)
+        g.reserve(0, 0, N // 8)
+        g.reserve(1, 0, N // 8)
+        inflight = []
+        for k in range(400):
+            kind = k % 4
+            n_owned = [int(rng.integers(1, 1 << 14)), int(rng.integers(1 << 14, 1 << 22)), int(rng.integers(1 << 22, 1 << 27)),
+                       int(rng.integers(1, 64)) * 4096 + int(rng.integers(-17, 18))][kind]
+            start = int(rng.integers(0, (N - n_owned) // 16 + 1)) * 16
+            n_avail = min(N - start, n_owned + int(rng.integers(0, 4)))
+            g.scan_async(n_owned, n_avail, d_input=int(buf.data_ptr()) + start, slot=k & 1)
+            inflight.append((k & 1, start, n_owned, n_avail))
+            if len(inflight) == 2:
+                sl, st, no, na = inflight.pop(0)
+                cnt, over = g.scan_finish(sl)
+                assert not over and cnt == expected(st, no, na), (k, st, no, na, cnt)
+        for sl, st, no, na in inflight:
+            cnt, over = g.scan_finish(sl)
+            assert not over and cnt == expected(st, no, na)
+    o.close()
+
+
 def test_random_fill_matches_cpu_twin_and_oracle(resolve):
     import torch
     n = 1 << 22
