@@ -118,6 +118,7 @@ struct ScanArgs {
     unsigned nbuf;                        // staging buffers per wave: 3 = emit two rounds late, 1 = emit at once (dense mode)
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
     unsigned n_tiles;
+    unsigned lb_trigger;           // 10 ns ticks after a round's aggregate went out before its look-back window may be loaded (PFAC_LBD)
     unsigned *ctl;                 // [0] batch ticket (device memory)
     uint4 *zero_next;              // the slot's OTHER control buffer: this launch zeroes it for the next one ...
     unsigned zero_vec;             // ... this many 16-byte units (no memset between back-to-back scans)
@@ -822,6 +823,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         struct Pend { bool on; unsigned r, g; unsigned long long tot, end; unsigned cnt; };
         Pend p1 = {false, 0, 0, 0, 0, 0}, p2 = {false, 0, 0, 0, 0, 0};
         LbWindow win = {};
+        unsigned long long t_pub = 0;          // when this workgroup's last aggregate went out (100 MHz ticks)
         // resolve a round: batch base from the look-back, then every compute wave's first record index
         auto resolve = [&](const Pend &p, const LbWindow *pre) {
             const unsigned long long excl = lookback(a.status, p.g, p.tot, lane, err, pre);
@@ -854,14 +856,36 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
             // (b) round r: wait for the counts, publish the aggregate
             const unsigned long long left = a.n_tiles - first;
             const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
-            if (!lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
+            // While waiting: once round r-1's aggregate has been out for lb_trigger ticks (3.8 us: time for the
+            // workgroups ahead of this one to have resolved THEIR round r-1, so the window ends at an inclusive prefix),
+            // start loading its look-back window -- the memory round trip then overlaps the rest of the arrivals
+            // instead of sitting in front of the next iteration.  Short rounds (sparse input) never get there and load
+            // the window after this round's aggregate went out, as before; loading it earlier than that costs them 12 %
+            // (the window then usually ends in aggregates only and a second, blocking one is needed), loading it
+            // this early gains the match-dense headline 7 %.
+            bool win_issued = !p1.on;
+            {
+                bool failed = false;
+                unsigned spins = 0;
+                if (!win_issued) {
+                    unsigned arr = lds_load(&hdr[H_ARRIVED + (r & 7)]);
+                    while (arr != n_valid && __builtin_amdgcn_s_memrealtime() - t_pub < (unsigned long long)a.lb_trigger) {
+                        if (++spins >= SPIN_MAX) { atomicOr(err, 4u); failed = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        arr = lds_load(&hdr[H_ARRIVED + (r & 7)]);
+                    }
+                    if (!failed && arr != n_valid) { lookback_issue(a.status, p1.g, lane, win); win_issued = true; }
+                }
+                if (failed || !lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
+            }
             if (trace) tr[1] = __builtin_amdgcn_s_memrealtime();
             const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
             const unsigned long long tot = wave_sum64(c);
             publish_aggregate(a.status, g_cur, tot, lane);
+            t_pub = __builtin_amdgcn_s_memrealtime();
             const Pend cur = {true, r, g_cur, tot, first + n_valid, c};
             // (c) round r-1 moves on: issue its look-back window now, finish it next iteration
-            if (p1.on) { lookback_issue(a.status, p1.g, lane, win); p2 = p1; p1.on = false; }
+            if (p1.on) { if (!win_issued) lookback_issue(a.status, p1.g, lane, win); p2 = p1; p1.on = false; }
             p1 = cur;
             if (lds_load(&hdr[H_URGENT + (r & 7)]) != 0) {  // a wave overflowed its staging: it is waiting for this base
                 if (p2.on) { resolve(p2, &win); p2.on = false; }
@@ -1225,7 +1249,8 @@ int ensure_status(pfac_ctx *ctx, Slot &s, uint64_t n_words) {
     uint64_t cap = n_words < 4096 ? 4096 : n_words + n_words / 4;
     const size_t region = align_up(64 + cap * 8 + 16, 256);
     HIP_TRY(ctx, hipMalloc((void **)&s.d_ctl, 2 * region));
-    HIP_TRY(ctx, hipMemset(s.d_ctl, 0, 2 * region));
+    // on the slot's own stream: it is a non-blocking stream, a null-stream memset is not ordered before the scan that follows
+    HIP_TRY(ctx, hipMemsetAsync(s.d_ctl, 0, 2 * region, s.stream));
     s.d_ctlbuf[0] = s.d_ctl;
     s.d_ctlbuf[1] = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(s.d_ctl) + region);
     s.clean[0] = s.clean[1] = cap;
@@ -1575,6 +1600,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;
         a.root_state = ctx->root_state;
+        a.lb_trigger = getenv("PFAC_LBD") ? (unsigned)atoi(getenv("PFAC_LBD")) : 380u;
         a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
         a.nbuf = dense ? 1u : (unsigned)NBUF;
         a.sparse_cap = ctx->stage_cap;
