@@ -409,6 +409,26 @@ def test_back_to_back_scans_of_varied_sizes(resolve):
     o.close()
 
 
+def test_first_scan_of_fresh_contexts(resolve):
+    """The very first scan of a new context uses control buffers that were allocated and zeroed a moment ago: the
+    zeroing must be ordered before the scan on the slot's (non-blocking) stream.  Many fresh contexts, one scan each."""
+    import torch
+    para = open(resolve("paragraph402"), "rb").read()
+    table = PfacTable.from_file(resolve("bytefile/10000byte"), 256)
+    n = 1 << 22
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    with GpuMatcher(0, 1) as g0:
+        g0.fill_random(buf, n, 0x5048465046414331)
+        g0.sync(0)
+    junk = [torch.full((1 << 20,), 0x7F, dtype=torch.uint8, device="cuda:0") for _ in range(8)]   # dirty memory to hand back
+    del junk
+    for k in range(60):
+        with GpuMatcher(0, 1) as g:
+            g.load_table(table)
+            g.reserve(0, 0, 1 << 12)
+            assert g.scan_resident(n, n, d_input=buf) == 1, k
+
+
 def test_random_fill_matches_cpu_twin_and_oracle(resolve):
     import torch
     n = 1 << 22
