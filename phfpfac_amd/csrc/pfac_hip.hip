@@ -224,17 +224,33 @@ __device__ __forceinline__ void publish_aggregate(unsigned long long *status, un
 // set and the kernel still terminates.  Batches are handed out in order and an aggregate is
 // published without waiting for anything, so every predecessor polled here belongs to a workgroup
 // that is running or done.
-constexpr int LB_WIN = 4;
+// Window widths (in waves = 64 predecessors each): the window the coordinator loads ahead of time (PRE) and the
+// windows the loop loads when that one did not reach an inclusive prefix (LOOP).  Narrow is better than wide: all
+// workgroups read the same few cache lines of look-back words while their owners write them, and the wider the
+// windows the longer those hot lines queue (4 x 64 -> 1 x 64: +11..15 % on the sparse workloads).
+#ifndef PFAC_LB_PRE
+#define PFAC_LB_PRE 1
+#endif
+#ifndef PFAC_LB_LOOP
+#define PFAC_LB_LOOP 1
+#endif
+constexpr int LB_PRE = PFAC_LB_PRE, LB_LOOP = PFAC_LB_LOOP, LB_MAX = LB_PRE > LB_LOOP ? LB_PRE : LB_LOOP;
+#ifndef PFAC_LB_LANES
+#define PFAC_LB_LANES 64
+#endif
+constexpr int LB_LANES = PFAC_LB_LANES;    // lanes of the last wave of a window that take part (fewer: a shorter window still)
+static_assert(LB_LANES == 64 || (LB_PRE == 1 && LB_LOOP == 1), "partial waves only with one-wave windows");
 struct LbWindow {
-    unsigned long long st[LB_WIN];
+    unsigned long long st[LB_PRE];
 };
-// Issue the loads of the window right behind `tile` (no wait): the coordinator does this one round
-// before it needs the answer, so the memory round trip overlaps the next round's arrivals.
+// Issue the loads of the window right behind `tile` (no wait): the coordinator does this ahead of the round in
+// which it needs the answer, so the memory round trip overlaps the arrivals.
 __device__ __forceinline__ void lookback_issue(unsigned long long *status, unsigned tile, int lane, LbWindow &w) {
 #pragma unroll
-    for (int k = 0; k < LB_WIN; k++) {
+    for (int k = 0; k < LB_PRE; k++) {
         const long long idx = (long long)tile - 1 - lane - WAVE * k;
-        w.st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
+        w.st[k] = 0;
+        if (lane < LB_LANES) w.st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
     }
 }
 // pre != nullptr: the first window was loaded earlier by lookback_issue().
@@ -247,20 +263,26 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
     bool failed = false;
     bool use_pre = pre != nullptr;
     while (top >= 0) {
-        unsigned long long st[LB_WIN];
+        const int nw = use_pre ? LB_PRE : LB_LOOP;    // width of this window (wave-uniform)
+        unsigned long long st[LB_MAX];
 #pragma unroll
-        for (int k = 0; k < LB_WIN; k++) {
+        for (int k = 0; k < LB_MAX; k++) {
             const long long idx = top - lane - WAVE * k;   // position WAVE*k + lane behind `top`
-            if (use_pre) st[k] = pre->st[k];
-            else st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
+            st[k] = 0;
+            if (k < nw) {
+                if (use_pre) st[k] = pre->st[k < LB_PRE ? k : 0];
+                else if (lane < LB_LANES) st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
+            }
         }
         use_pre = false;
         // first unpublished and first inclusive position in the window (wave-uniform)
-        int pz = LB_WIN * WAVE, pi = LB_WIN * WAVE;
+        const unsigned long long part = LB_LANES == 64 ? ~0ull : ((1ull << (LB_LANES & 63)) - 1ull);
+        int pz = (nw - 1) * WAVE + LB_LANES, pi = pz;
 #pragma unroll
-        for (int k = LB_WIN - 1; k >= 0; k--) {
-            const unsigned long long z = __ballot((st[k] >> 62) == 0);
-            const unsigned long long in = __ballot((st[k] >> 62) == 2);
+        for (int k = LB_MAX - 1; k >= 0; k--) {
+            if (k >= nw) continue;
+            const unsigned long long z = __ballot((st[k] >> 62) == 0) & part;
+            const unsigned long long in = __ballot((st[k] >> 62) == 2) & part;
             if (z) pz = WAVE * k + __ffsll((long long)z) - 1;
             if (in) pi = WAVE * k + __ffsll((long long)in) - 1;
         }
@@ -272,8 +294,8 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
         }
         unsigned long long v = 0;
 #pragma unroll
-        for (int k = 0; k < LB_WIN; k++)
-            if (WAVE * k + lane <= upto) v += st[k] & ST_VAL;
+        for (int k = 0; k < LB_MAX; k++)
+            if (k < nw && WAVE * k + lane <= upto) v += st[k] & ST_VAL;
         excl += wave_sum64(v);
         if (pi < pz) break;                           // reached a predecessor with an inclusive prefix
         top -= upto + 1;                              // consumed the published aggregates; continue behind them
@@ -1600,7 +1622,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;
         a.root_state = ctx->root_state;
-        a.lb_trigger = getenv("PFAC_LBD") ? (unsigned)atoi(getenv("PFAC_LBD")) : 380u;
+        a.lb_trigger = getenv("PFAC_LBD") ? (unsigned)atoi(getenv("PFAC_LBD")) : 300u;
         a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
         a.nbuf = dense ? 1u : (unsigned)NBUF;
         a.sparse_cap = ctx->stage_cap;
