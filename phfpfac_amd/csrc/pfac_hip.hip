@@ -88,6 +88,9 @@ constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
 constexpr int CAPW_DENSE = 2048;
 constexpr int PW_FIXED_DENSE = WTILE + QCAP * 2 + CAPW_DENSE * 4;
 
+// One look-back word per 64 bytes: eight owners no longer write the cache line their successors are polling
+// (sparse workloads +2.5 %); the price is 64 B instead of 8 B of control memory per batch.
+constexpr long long ST_STRIDE = 8;         // u64 words between consecutive look-back words
 constexpr unsigned long long ST_AGG = 1ull << 62;
 constexpr unsigned long long ST_INCL = 2ull << 62;
 constexpr unsigned long long ST_VAL = (1ull << 62) - 1;
@@ -212,7 +215,7 @@ __device__ __forceinline__ void st_store(unsigned long long *p, unsigned long lo
 
 // A tile first publishes its own count (aggregate); tile 0's count is already its inclusive prefix.
 __device__ __forceinline__ void publish_aggregate(unsigned long long *status, unsigned tile, unsigned long long tot, int lane) {
-    if (lane == 0) st_store(&status[tile], (tile == 0 ? ST_INCL : ST_AGG) | tot);
+    if (lane == 0) st_store(&status[(long long)tile * ST_STRIDE], (tile == 0 ? ST_INCL : ST_AGG) | tot);
 }
 
 // All 64 lanes of one wave.  Returns the number of matches in all batches before `tile`
@@ -250,7 +253,7 @@ __device__ __forceinline__ void lookback_issue(unsigned long long *status, unsig
     for (int k = 0; k < LB_PRE; k++) {
         const long long idx = (long long)tile - 1 - lane - WAVE * k;
         w.st[k] = 0;
-        if (lane < LB_LANES) w.st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
+        if (lane < LB_LANES) w.st[k] = idx >= 0 ? st_load(&status[idx * ST_STRIDE]) : ST_INCL;   // before batch 0: inclusive prefix 0
     }
 }
 // pre != nullptr: the first window was loaded earlier by lookback_issue().
@@ -271,7 +274,7 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
             st[k] = 0;
             if (k < nw) {
                 if (use_pre) st[k] = pre->st[k < LB_PRE ? k : 0];
-                else if (lane < LB_LANES) st[k] = idx >= 0 ? st_load(&status[idx]) : ST_INCL;   // before batch 0: inclusive prefix 0
+                else if (lane < LB_LANES) st[k] = idx >= 0 ? st_load(&status[idx * ST_STRIDE]) : ST_INCL;   // before batch 0: inclusive prefix 0
             }
         }
         use_pre = false;
@@ -304,7 +307,7 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
         if (lane == 0) atomicOr(err, 1u);
         excl = 0;
     }
-    if (lane == 0) st_store(&status[tile], ST_INCL | ((excl + tot) & ST_VAL));
+    if (lane == 0) st_store(&status[(long long)tile * ST_STRIDE], ST_INCL | ((excl + tot) & ST_VAL));
     return excl;
 }
 
@@ -1598,7 +1601,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     // slot has two control buffers: every scan zeroes, in its own prologue, what the next scan needs in the other
     // one, so back-to-back scans of similar size need no memset; anything else falls back to one.
     const uint64_t n_batches = (n_tiles + wpb - 2) / (wpb - 1);
-    const uint64_t need = n_batches + 6ull * ctx->grid_blocks + 8;
+    const uint64_t need = (n_batches + 6ull * ctx->grid_blocks + 8) * (uint64_t)ST_STRIDE;   // u64 words
     rc = ensure_status(ctx, s, need);
     if (rc) return rc;
     unsigned *const cur = s.d_ctlbuf[s.flip], *const nxt = s.d_ctlbuf[1 - s.flip];
