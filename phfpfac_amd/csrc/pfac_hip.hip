@@ -94,6 +94,18 @@ constexpr long long ST_STRIDE = 8;         // u64 words between consecutive look
 constexpr unsigned long long ST_AGG = 1ull << 62;
 constexpr unsigned long long ST_INCL = 2ull << 62;
 constexpr unsigned long long ST_VAL = (1ull << 62) - 1;
+// Batch tickets: one address sustains ~85 M atomics/s, and at 4 TB/s with 60 KiB per ticket the workgroups ask for
+// 65 M/s -- the single counter was the floor of the whole kernel (3.9 us per round with the scan compiled out).  So
+// there are TICKET_WAYS counters, 256 bytes apart: workgroup j draws from counter j % ways and holds batches
+// ticket * ways + j % ways.  Ids stay monotone per workgroup (it leaves when ITS counter runs past the end), every
+// batch below the end is drawn by somebody as long as every residue class has a workgroup (ways <= grid), and a
+// look-back that meets a batch nobody has drawn yet simply sees "not published" and polls: the residue class with
+// the smallest undrawn batch never waits for a larger one, so somebody always makes progress.
+#ifndef PFAC_TICKET_WAYS
+#define PFAC_TICKET_WAYS 4
+#endif
+constexpr unsigned TICKET_WAYS = PFAC_TICKET_WAYS;
+constexpr unsigned CTL_WORDS = 64u * TICKET_WAYS;      // control header in 32-bit words: one 256-byte line per counter
 constexpr unsigned SPIN_MAX = 1u << 22;    // bounded spins: ~0.5 s of LDS polls, seconds of global polls
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -122,7 +134,8 @@ struct ScanArgs {
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
     unsigned n_tiles;
     unsigned lb_trigger;           // 10 ns ticks after a round's aggregate went out before its look-back window may be loaded (PFAC_LBD)
-    unsigned *ctl;                 // [0] batch ticket (device memory)
+    unsigned *ctl;                 // batch ticket counters (device memory), 64 words apart
+    unsigned ticket_ways;          // counters in use: min(TICKET_WAYS, grid)
     uint4 *zero_next;              // the slot's OTHER control buffer: this launch zeroes it for the next one ...
     unsigned zero_vec;             // ... this many 16-byte units (no memset between back-to-back scans)
     unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy:
@@ -822,7 +835,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         // round trip never blocks the coordinator
         auto ticket = [&]() -> unsigned {
             unsigned g = 0;
-            if (lane == 0) g = atomicAdd(&a.ctl[0], 1u);
+            if (lane == 0) g = atomicAdd(&a.ctl[(blockIdx.x % a.ticket_ways) * 64u], 1u) * a.ticket_ways + blockIdx.x % a.ticket_ways;
             return g;                          // valid in lane 0 (not waited for here)
         };
         auto publish_batch = [&](unsigned r, unsigned g_lane0) -> unsigned {   // ring entry of round r; returns batch id
@@ -1272,7 +1285,7 @@ int ensure_status(pfac_ctx *ctx, Slot &s, uint64_t n_words) {
     }
     s.d_ctl = nullptr;
     uint64_t cap = n_words < 4096 ? 4096 : n_words + n_words / 4;
-    const size_t region = align_up(64 + cap * 8 + 16, 256);
+    const size_t region = align_up(CTL_WORDS * 4 + cap * 8 + 16, 256);
     HIP_TRY(ctx, hipMalloc((void **)&s.d_ctl, 2 * region));
     // on the slot's own stream: it is a non-blocking stream, a null-stream memset is not ordered before the scan that follows
     HIP_TRY(ctx, hipMemsetAsync(s.d_ctl, 0, 2 * region, s.stream));
@@ -1606,7 +1619,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     if (rc) return rc;
     unsigned *const cur = s.d_ctlbuf[s.flip], *const nxt = s.d_ctlbuf[1 - s.flip];
     if (n_tiles > 0 && s.clean[s.flip] < need)
-        HIP_TRY(ctx, hipMemsetAsync(cur, 0, 64 + align_up(need * 8, 16), s.stream));
+        HIP_TRY(ctx, hipMemsetAsync(cur, 0, CTL_WORDS * 4 + align_up(need * 8, 16), s.stream));
     HIP_TRY(ctx, hipEventRecord(s.ev0, s.stream));
     if (n_tiles > 0) {
         ScanArgs a;
@@ -1632,9 +1645,9 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = cur;
         a.zero_next = reinterpret_cast<uint4 *>(nxt);
-        a.zero_vec = (unsigned)((64 + align_up(need * 8, 16)) / 16);
+        a.zero_vec = (unsigned)((CTL_WORDS * 4 + align_up(need * 8, 16)) / 16);
         a.res = s.d_res;
-        a.status = reinterpret_cast<unsigned long long *>(cur + 16);
+        a.status = reinterpret_cast<unsigned long long *>(cur + CTL_WORDS);
         a.dbg = nullptr;
         if (getenv("PFAC_TRACE")) {
             if (!s.d_dbg) HIP_TRY(ctx, hipMalloc((void **)&s.d_dbg, 8 * 64 * 32 * 8));
@@ -1643,6 +1656,9 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         }
         const uint64_t want = n_batches;
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
+        a.ticket_ways = grid < TICKET_WAYS ? (unsigned)grid : TICKET_WAYS;
+        if (getenv("PFAC_TICKET_WAYS") && atoi(getenv("PFAC_TICKET_WAYS")) >= 1 && (unsigned)atoi(getenv("PFAC_TICKET_WAYS")) < a.ticket_ways)
+            a.ticket_ways = (unsigned)atoi(getenv("PFAC_TICKET_WAYS"));
         void *kargs[] = {&a};
         HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
         s.clean[s.flip] = 0;                   // used by this scan
