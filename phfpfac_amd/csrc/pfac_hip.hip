@@ -165,6 +165,14 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x) {
     return x;
 }
 __device__ __forceinline__ unsigned bcast_last(unsigned x) { return __builtin_amdgcn_readlane(x, WAVE - 1); }
+// Sum of a 62-bit value over the wave without LDS round trips: three DPP scans over 24/24/14-bit slices (the
+// coordinator sums on its critical path every round; six dependent ds_bpermute pairs cost it ~0.3 us).
+__device__ __forceinline__ unsigned long long wave_sum62(unsigned long long x) {
+    const unsigned lo = (unsigned)x & 0xFFFFFFu, mid = (unsigned)(x >> 24) & 0xFFFFFFu, hi = (unsigned)(x >> 48);
+    const unsigned long long slo = bcast_last(wave_incl_scan(lo)), smid = bcast_last(wave_incl_scan(mid)),
+                             shi = bcast_last(wave_incl_scan(hi));
+    return slo + (smid << 24) + (shi << 48);
+}
 
 // LDS written by some lanes of a wave and read by others of the SAME wave:
 // the LDS executes one wave's instructions in order; this keeps the compiler
@@ -312,7 +320,7 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
 #pragma unroll
         for (int k = 0; k < LB_MAX; k++)
             if (k < nw && WAVE * k + lane <= upto) v += st[k] & ST_VAL;
-        excl += wave_sum64(v);
+        excl += wave_sum62(v);
         if (pi < pz) break;                           // reached a predecessor with an inclusive prefix
         top -= upto + 1;                              // consumed the published aggregates; continue behind them
     }
@@ -918,7 +926,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
             }
             if (trace) tr[1] = __builtin_amdgcn_s_memrealtime();
             const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
-            const unsigned long long tot = wave_sum64(c);
+            const unsigned long long tot = bcast_last(wave_incl_scan(c));   // 15 tile counts of < 2^22 each
             publish_aggregate(a.status, g_cur, tot, lane);
             t_pub = __builtin_amdgcn_s_memrealtime();
             const Pend cur = {true, r, g_cur, tot, first + n_valid, c};
