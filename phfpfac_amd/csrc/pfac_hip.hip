@@ -727,7 +727,18 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
         rec.state = v >> 12;
         a.out[base] = rec;
     }
-    for (unsigned i = head + 2u * (unsigned)lane; i < cnt; i += 2u * WAVE) {
+    unsigned i = head + 2u * (unsigned)lane;
+    // the usual case, four records per lane per trip: both LDS reads are in flight before either pair is stored
+    // (wave-uniform condition: everything up to the end of this trip exists and fits)
+    while (i - 2u * (unsigned)lane + 4u * WAVE <= cnt && base + cnt <= a.out_cap) {
+        const unsigned a0 = stage[i], a1 = stage[i + 1], b0 = stage[i + 2u * WAVE], b1 = stage[i + 2u * WAVE + 1];
+        u32x4 pa = {tb | (a0 & 0xFFFu), a0 >> 12, tb | (a1 & 0xFFFu), a1 >> 12};
+        u32x4 pb = {tb | (b0 & 0xFFFu), b0 >> 12, tb | (b1 & 0xFFFu), b1 >> 12};
+        *reinterpret_cast<u32x4 *>(&a.out[base + i]) = pa;
+        *reinterpret_cast<u32x4 *>(&a.out[base + i + 2u * WAVE]) = pb;
+        i += 4u * WAVE;
+    }
+    for (; i < cnt; i += 2u * WAVE) {
         const unsigned v0 = stage[i];
         if (i + 1 < cnt && base + i + 1 < a.out_cap) {
             const unsigned v1 = stage[i + 1];

@@ -11,6 +11,6 @@ t = PfacTable.from_file(os.path.join(DATA, sys.argv[1] if len(sys.argv) > 1 else
 with GpuMatcher(0, 1) as g:
     g.load_table(t); g.fill_tiled(buf, N, para); g.reserve(0, 0, N // 8)
     ms = []
-    for _ in range(24):
+    for _ in range(int(os.environ.get("N_LAUNCH", "24"))):
         g.scan_async(N, N, d_input=buf); g.scan_finish(0); ms.append(g.elapsed_ms(0))
 print(" ".join("%.3f" % x for x in ms))
