@@ -33,5 +33,18 @@ for row in csv.DictReader(open(ks)):
     if "pfac_scan_kernel" in row["Name"]:
         out["kernel_stats_avg_ns"] = float(row["AverageNs"]); out["kernel_stats_max_ns"] = float(row["MaxNs"])
         out["kernel_stats_calls"] = int(row["Calls"])
+# per-launch durations from the kernel trace: the --stats average covers EVERY launch of the command (setup, clock
+# settling, warm-up, timed steps); bench.py's roofline uses the timed steps only = the last `steps` launches
+kt = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+if kt:
+    rows = [r for r in csv.DictReader(open(kt[0])) if "pfac_scan_kernel" in r.get("Kernel_Name", "")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    if dur:
+        k = int(os.environ.get("TIMED_STEPS", "20"))
+        out["kernel_trace_launches"] = len(dur)
+        out["kernel_trace_last_steps"] = k
+        out["kernel_trace_last_steps_avg_ns"] = sum(dur[-k:]) / len(dur[-k:])
+        out["kernel_trace_first_launches_ns"] = dur[:12]
 json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
