@@ -1694,7 +1694,9 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     Slot &s = ctx->slots[slot];
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_scan_finish without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    // wait for THIS scan's end event, not for the stream: another slot may share the stream (launch pipelining), and
+    // its scan -- enqueued after this one -- should keep the GPU busy while the host reads this result
+    HIP_TRY(ctx, hipEventSynchronize(s.ev1));
     s.pending = false;
     const uint64_t total = ((uint64_t)s.h_ctl[1] << 32) | s.h_ctl[0];
     if (n_matches) *n_matches = total;
