@@ -37,7 +37,7 @@ typedef enum {
     PFAC_E_HIP = -6,        /* a HIP runtime call failed; see pfac_last_error() */
     PFAC_E_STATE = -7,      /* call order violated (scan before table upload, ...) */
     PFAC_E_OVERFLOW = -8,   /* more matches than the record buffer holds (count is still exact) */
-    PFAC_E_INTERNAL = -9    /* kernel reported an internal fault (look-back timeout) */
+    PFAC_E_INTERNAL = -9    /* kernel reported an internal fault (a bounded wait of the scan protocol timed out) */
 } pfac_status;
 
 /* ------------------------------------------------------------------ */
@@ -126,6 +126,16 @@ typedef struct pfac_record {
     uint32_t pos;       /* start offset, relative to the first byte of the scanned range */
     uint32_t state;     /* final state reached (== index into idmap) */
 } pfac_record;
+/*
+ * On the DEVICE the scan writes the COMPACT form of the same ordered list (half the HBM and PCIe bytes): one 32-bit
+ * word per match,  (pos & 4095) | state << 12,  plus tile_first[t] = index of the first record of 4 KiB input tile t
+ * (tile_first[n_tiles] = total), so  pos = t * 4096 + (word & 4095)  for tile_first[t] <= i < tile_first[t+1].
+ * Automata with more than 2^20 final states keep 8-byte pfac_record on the device as well
+ * (pfac_scan_format tells which).  pfac_records_d2h / pfac_records_expand deliver pfac_record either way.
+ */
+#define PFAC_TILE_BYTES 4096
+#define PFAC_PACKED_POS(word) ((uint32_t)(word) & 4095u)
+#define PFAC_PACKED_STATE(word) ((uint32_t)(word) >> 12)
 /* idmap == NULL: rec.state already holds the pattern id (the output of pfac_merge_partitions). */
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap);
 /* Same bytes, produced by n_threads host threads (size pass, prefix sum, format + pwrite in place); the serial
@@ -133,6 +143,11 @@ int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64
  * serial emitter for small n, n_threads < 2 or pipes. */
 int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
                              int n_threads);
+/* The same text straight from the compact device form (words + tile index as pfac_records_d2h_packed delivers
+ * them): position = base + t * 4096 + PFAC_PACKED_POS(word), pattern = idmap[PFAC_PACKED_STATE(word)].
+ * n_threads < 2: serial. */
+int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_first, uint64_t n_tiles, uint64_t base,
+                         const int32_t *idmap, int n_threads);
 /* Merge of per-partition match lists, replaces main.cc:304-324.  lists[k] (counts[k] records, sorted by
  * position as the scan emits them) comes from partition k of pfac_table_build_file_part(); the result is
  * ordered by (position, partition) -- i.e. by (position, pattern length), the reference's output order -- and
@@ -172,7 +187,7 @@ void pfac_host_free(void *p);
  * one tile + 512 B for the same reason). */
 int pfac_slot_reserve(pfac_ctx *ctx, int slot, uint64_t input_bytes, uint64_t record_capacity);
 void *pfac_slot_input(pfac_ctx *ctx, int slot);          /* device pointer, 256-B aligned */
-pfac_record *pfac_slot_records(pfac_ctx *ctx, int slot); /* device pointer */
+void *pfac_slot_records(pfac_ctx *ctx, int slot);        /* device pointer (record_capacity x 8 bytes, either record form) */
 void *pfac_slot_stream(pfac_ctx *ctx, int slot);         /* the slot's hipStream_t */
 /* Use an EXTERNAL stream (e.g. torch's current stream) for a slot; NULL restores the slot's own. */
 int pfac_slot_set_stream(pfac_ctx *ctx, int slot, void *stream_handle);
@@ -188,13 +203,15 @@ int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, u
  *   n_avail   bytes readable from d_input, n_owned <= n_avail; walks that
  *             start in the owned range may read up to n_avail (the halo of
  *             max_pat_len-1 bytes that belongs to the next shard) and never beyond
- *   d_records device pointer for the ordered compact records, NULL = the slot's
+ *   d_records device pointer for the ordered compact records, 16-B aligned, NULL = the slot's;
+ *             capacity x 4 bytes are written in the compact form, capacity x 8 in the wide one
  *   capacity  records that fit; the count is exact even when it overflows
  * Records come out sorted by (pos, pattern length) == the reference's output
- * order (main.cc:341-349).  Asynchronous on the slot's stream.
+ * order (main.cc:341-349); the tile index of the compact form lives in the slot.
+ * Asynchronous on the slot's stream.
  */
 int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_owned, uint64_t n_avail,
-                    pfac_record *d_records, uint64_t capacity);
+                    void *d_records, uint64_t capacity);
 /* Wait for the slot and fetch the exact number of matches.  Returns
  * PFAC_E_OVERFLOW (with *n_matches set) when capacity was exceeded. */
 int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches);
@@ -203,13 +220,22 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches);
 int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms);
 /* D2H of records [first, first+n) (the compact replacement of the dense
  * cudaMemcpy D2H, master_kernel.cu:428).  Asynchronous; pfac_slot_sync() completes it. */
-int pfac_records_d2h(pfac_ctx *ctx, int slot, const pfac_record *d_records, pfac_record *host, uint64_t first, uint64_t n);
+int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record *host, uint64_t first, uint64_t n);
 int pfac_slot_sync(pfac_ctx *ctx, int slot);
+/* Record form of the slot's last scan: *packed = 1 compact words + tile index, 0 pfac_record; *n_tiles = tiles scanned. */
+int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles);
+/* Records [first, first+n) of the slot's last scan as pfac_record in DEVICE memory (d_out, 8-B aligned), on the slot's
+ * stream -- for consumers that stay on the GPU (the RCCL record gather). */
+int pfac_records_expand(pfac_ctx *ctx, int slot, const void *d_records, uint64_t first, uint64_t n, pfac_record *d_out);
+/* D2H of the compact form itself: words [0, n) and the n_tiles + 1 entries of the tile index (4 bytes per match over
+ * PCIe instead of 8; pfac_emit_packed() prints from it).  PFAC_E_STATE when the last scan was not compact. */
+int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n,
+                            uint64_t *host_tile_first);
 
 /* Order-independent 64-bit checksum of n records (sum over records of
  * mix(base+pos, idmap[state])), computed on the GPU; used for full-size
  * parity checks where materialising the text is not practical. */
-int pfac_records_checksum(pfac_ctx *ctx, int slot, const pfac_record *d_records, uint64_t n, uint64_t base,
+int pfac_records_checksum(pfac_ctx *ctx, int slot, const void *d_records, uint64_t n, uint64_t base,
                           uint64_t *checksum);
 
 /* Synthetic input generators, written straight into device memory (the

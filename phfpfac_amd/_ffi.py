@@ -68,14 +68,15 @@ HOST_SYMBOLS = (
     "pfac_table_build_file", "pfac_table_build_file_escaped", "pfac_table_build_mem", "pfac_table_build_file_part",
     "pfac_table_build_mem_part", "pfac_merge_partitions", "pfac_table_free", "pfac_table_lookup",
     "pfac_table_blob_words", "pfac_table_to_blob", "pfac_table_from_blob", "pfac_table_from_reference_arrays",
-    "pfac_emit_records", "pfac_emit_records_mt",
+    "pfac_emit_records", "pfac_emit_records_mt", "pfac_emit_packed",
 )
 HIP_SYMBOLS = (
     "pfac_device_count", "pfac_ctx_create", "pfac_ctx_destroy", "pfac_last_error", "pfac_table_upload",
     "pfac_table_upload_device", "pfac_host_alloc", "pfac_host_free", "pfac_slot_reserve", "pfac_slot_input",
     "pfac_slot_records", "pfac_slot_stream", "pfac_slot_set_stream", "pfac_slot_h2d", "pfac_scan_async",
     "pfac_scan_finish", "pfac_scan_elapsed_ms", "pfac_records_d2h", "pfac_slot_sync", "pfac_records_checksum",
-    "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_trace_table_compat",
+    "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_trace_table_compat", "pfac_scan_format",
+    "pfac_records_expand", "pfac_records_d2h_packed",
 )
 
 _host = None
@@ -113,6 +114,8 @@ def host_lib() -> C.CDLL:
         L.pfac_emit_records.restype = C.c_int64
         L.pfac_emit_records_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.pfac_emit_records_mt.restype = C.c_int64
+        L.pfac_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        L.pfac_emit_packed.restype = C.c_int64
         _host = L
     return _host
 
@@ -159,6 +162,9 @@ def hip_lib() -> C.CDLL:
         L.pfac_scan_finish.argtypes = [vp, i, C.POINTER(u64)]
         L.pfac_scan_elapsed_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
         L.pfac_records_d2h.argtypes = [vp, i, vp, vp, u64, u64]
+        L.pfac_scan_format.argtypes = [vp, i, C.POINTER(i), C.POINTER(u64)]
+        L.pfac_records_expand.argtypes = [vp, i, vp, u64, u64, vp]
+        L.pfac_records_d2h_packed.argtypes = [vp, i, vp, vp, u64, vp]
         L.pfac_slot_sync.argtypes = [vp, i]
         L.pfac_records_checksum.argtypes = [vp, i, vp, u64, u64, C.POINTER(u64)]
         L.pfac_fill_tiled.argtypes = [vp, i, vp, u64, vp, C.c_uint32, u64]

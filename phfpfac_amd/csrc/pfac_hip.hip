@@ -6,32 +6,38 @@
  * GPU_Free_memory :457-524).  Written for 64-wide wavefronts; not a
  * translation: the reference gives every offset a dense max_pat_len-slot
  * result row (4*max_pat_len bytes of HBM traffic per input byte, three times
- * over); this kernel emits compact, globally ORDERED 8-byte records in a
- * single pass over the input.
+ * over); this kernel emits compact, globally ORDERED records in a single pass
+ * over the input: one 32-bit word  pos_in_tile:12 | final_state:20  per match
+ * plus one 64-bit first-record index per 4 KiB tile (automata with more than
+ * 2^20 final states fall back to 8-byte {pos, state} records).
  *
  * Kernel structure (one persistent workgroup per CU = up to 15 compute waves + 1 coordinator wave;
  * the unit of work is a WAVE TILE, 4 KiB of input owned by one wavefront; no workgroup barrier in the loop):
  *   ticket   the coordinator takes one BATCH of tiles (one per compute wave) per round with a single
- *            global atomic, three rounds ahead; batches are handed out in order, so whoever holds
- *            batch G knows every batch < G is held by a running workgroup
+ *            global atomic, three rounds ahead (four interleaved ticket counters)
  *   stage    each wave loads its 4 KiB with 16-B-per-lane buffer loads (hardware bounds check ->
  *            bytes past n_avail read as 0), one round ahead, and mirrors them + the max_pat_len-1
  *            halo into its private LDS region
  *   root     32-bit "has a root edge" mask per lane per 32 contiguous bytes (two halves per tile): SWAR
  *            compare + v_dot4 when the root has a single edge, else one LDS flag lookup per byte (mk.cu:41)
- *   compact  DPP prefix sums append the survivors' positions, in order, to a FIFO in LDS; a round of
- *            64 (x NWALK) survivors runs whenever that many are pending, so lanes stay dense
- *   walk     straight-line, predicated: root row and the dense depth-1 rows from LDS, deeper states
- *            through the perfect hash  state = PHF(state, byte)  from LDS (small tables) or L2
- *            (large: 2-4 walks per lane, slots fused with the next state's r[] so a step is one
- *            gather); final states are recorded as they are met                     (mk.cu:49-71)
+ *   level 2  most walks die on their second byte, so survivors are classified before any walk: DEEP when the
+ *            byte pair starts a path of length 2 in the trie (bit-parallel SWAR compare for a single-edge root
+ *            with <= 2 grandchildren, else one lookup per survivor in a 2-byte-prefix bitmap in LDS), SHALLOW-FINAL
+ *            when they are not deep but the depth-1 state is final (exactly one record, known without a walk);
+ *            everything else is dropped on the spot
+ *   compact  DPP prefix sums append the kept survivors' positions, in order, to a FIFO in LDS; a tile without deep
+ *            survivors writes its records straight to the staging buffer instead (no FIFO, no walk)
+ *   walk     rounds of 64 (x NWALK) FIFO entries; straight-line, predicated: root row and the dense depth-1 rows
+ *            from LDS, deeper states through the perfect hash  state = PHF(state, byte)  from LDS (small tables)
+ *            or L2 (large: 2-4 walks per lane, slots fused with the next state's r[] so a step is one gather);
+ *            final states are recorded as they are met (mk.cu:49-71); a round without deep entries skips the walk
  *   stage    records (pos:12 | state:20) go to an LDS staging buffer in (position, length) order
  *   order    per-wave counts -> coordinator -> batch aggregate -> decoupled look-back over batches
  *            (8-byte {flag,value} words, relaxed agent-scope atomics), pipelined over three rounds;
  *            the coordinator writes every wave's first record index back to LDS
- *   emit     two rounds later the wave copies its staged records to global memory, 16 B per lane --
- *            globally sorted by (position, pattern length), the reference's output order
- *            (main.cc:341-349).  Tiles with more records than the staging buffer holds are
+ *   emit     two rounds later the wave copies its staged words to global memory, 16 B per lane, and stores the
+ *            tile's first record index -- globally sorted by (position, pattern length), the reference's output
+ *            order (main.cc:341-349).  Tiles with more records than the staging buffer holds are
  *            re-walked writing straight to global memory; "dense mode" (one big staging buffer,
  *            synchronous emission) takes over when most tiles are like that.
  */
@@ -75,11 +81,14 @@ constexpr int SH_HDR = 0;                  // round rings (H_* below)
 constexpr int SH_S0 = SH_HDR + 2048;
 constexpr int SH_FTAB = SH_S0 + 256 * 4;
 constexpr int SH_D1IDX = SH_FTAB + 8 * 256; // 256 x u8: dense-row index of the depth-1 state reached on each root byte
-constexpr int SH_D1 = SH_D1IDX + 256;      // d1_rows dense rows int32[256] (the hot first-level transition rows)
+constexpr int SH_FIN = SH_D1IDX + 256;     // 256 x u8: 1 where the depth-1 state reached on that root byte is final
+constexpr int SH_D1 = SH_FIN + 256;        // d1_rows dense rows int32[256] (the hot first-level transition rows)
 constexpr int D1_MAX = 32;                 // at most this many depth-1 states get a dense row (else none do)
 constexpr int D1_STATE_BITS = 20;          // packed dense-row entry (FUSED): state | index of its r[] << 20
 constexpr int D1_N2_MAX = 2048;            // ... so at most this many depth-2 states (the entry stays positive)
-// the PHF tables (variant 0) follow the dense rows: SH_D1 + d1_rows * 1024
+// the PHF tables (variant 0) follow the dense rows: SH_D1 + d1_rows * 1024; the 2-byte-prefix bitmap (bm2_rows x 32
+// bytes) sits at ScanArgs::sh_bm2, behind them
+constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
 constexpr int NBUF = 3;                    // staging buffers: a tile's records are emitted two rounds later
 constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
@@ -106,15 +115,19 @@ constexpr unsigned long long ST_VAL = (1ull << 62) - 1;
 #endif
 constexpr unsigned TICKET_WAYS = PFAC_TICKET_WAYS;
 constexpr unsigned CTL_WORDS = 64u * TICKET_WAYS;      // control header in 32-bit words: one 256-byte line per counter
-constexpr unsigned SPIN_MAX = 1u << 22;    // bounded spins: ~0.5 s of LDS polls, seconds of global polls
+constexpr unsigned SPIN_MAX = 1u << 22;    // bounded spins (default; PFAC_SPIN_MAX): ~0.5 s of LDS polls, seconds of global polls
+// words of the control header (first ticket line) the kernel reports through: device memory, ordinary device atomics
+constexpr unsigned CTL_ERR = 32, CTL_OVF = 33, CTL_DONE = 34;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ScanArgs {
     const unsigned char *in;
     unsigned long long n_owned, n_avail;
-    pfac_record *out;
+    void *out;                            // packed: unsigned[out_cap] (pos:12 | state:20); else pfac_record[out_cap]
     unsigned long long out_cap;
+    unsigned long long *tile_first;       // [n_tiles + 1]: index of each tile's first record; [n_tiles] = total
+    unsigned packed;                      // record format of this scan (1: 4-byte words + tile_first, 0: 8-byte records)
     const int *s0;
     const int *r;
     const int2 *T;
@@ -129,19 +142,31 @@ struct ScanArgs {
     int d1_n2;                            // > 0: a dense-row entry is  state | index into d1r2 << 20  (or -1)
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
     int root_state;                       // ROOT == 1: the state that byte leads to (every survivor starts there)
+    // level-2 filter (which survivors can go beyond their second byte):
+    //   0 off: every survivor is walked        1 (ROOT == 1): SWAR compare with <= 2 child bytes of root_state
+    //   2: one lookup per survivor in the 2-byte-prefix bitmap (bm2_rows = 256 rows of 32 bytes; ROOT == 1: its one row)
+    int l2f_mode;
+    unsigned child0, child1;              // mode 1: the child bytes, replicated x4 (n_child 1: child1 == child0)
+    int n_child;                          // mode 1: 0 (nothing is ever deep), 1 or 2
+    const unsigned char *bm2;             // mode 2: bit (b0 << 8 | b1) set iff a path b0 b1 leaves the root
+    int bm2_rows, sh_bm2;                 // rows staged in LDS (256, or 1 = the root byte's row) at this LDS offset
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
     unsigned nbuf;                        // staging buffers per wave: 3 = emit two rounds late, 1 = emit at once (dense mode)
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
     unsigned n_tiles;
     unsigned lb_trigger;           // 10 ns ticks after a round's aggregate went out before its look-back window may be loaded (PFAC_LBD)
-    unsigned *ctl;                 // batch ticket counters (device memory), 64 words apart
+    unsigned spin_max;             // bound of every spin loop
+    unsigned fault;                // test knob (PFAC_FAULT): bit 0 = workgroup 1 never publishes its second batch
+    unsigned *ctl;                 // batch ticket counters (device memory), 64 words apart; [CTL_ERR/OVF/DONE]: error
+                                   // flags, tiles denser than sparse_cap, workgroups that have left
     unsigned ticket_ways;          // counters in use: min(TICKET_WAYS, grid)
     uint4 *zero_next;              // the slot's OTHER control buffer: this launch zeroes it for the next one ...
     unsigned zero_vec;             // ... this many 16-byte units (no memset between back-to-back scans)
-    unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy:
-                                   // [0..1] total matches (u64), [2] error flags, [3] tiles denser than sparse_cap
+    unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy, written with
+                                   // plain stores only: [0..1] total matches (u64) by the workgroup that resolves the last
+                                   // batch, [2] error flags and [3] tiles denser than sparse_cap by the last workgroup to leave
     unsigned long long *status;    // one look-back word per batch
-    unsigned long long *dbg;       // PFAC_TRACE only: per-round timestamps (10 ns units), else null
+    unsigned long long *dbg;       // PFAC_TRACE_BUILD only: per-round timestamps (10 ns units), else null
 };
 
 // ---------------------------------------------------------------------------
@@ -190,8 +215,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 // runs the decoupled look-back over BATCHES (a few hundred are in flight chip-wide, so the window is
 // short), while the compute waves are already scanning the next round; they pick the batch's
 // record base up from LDS when they emit, one round later.  No workgroup barrier in the loop.
-// Whoever holds batch G knows every batch < G is held by a running workgroup -- all the look-back
-// needs; nothing depends on dispatch order, residency or placement.
+// With TICKET_WAYS counters batch ids are monotone per workgroup and per residue class only: a look-back may meet
+// a batch nobody has drawn yet and polls it; liveness needs a RESIDENT workgroup in every residue class (one
+// workgroup per CU on a GPU this launch can fill gives that; otherwise the bounded spins end the scan with
+// PFAC_E_INTERNAL instead of hanging).  Nothing depends on dispatch order or placement.
 //
 // LDS header (unsigned words), rings of 8 rounds indexed by r & 7:
 constexpr int RING = 8;
@@ -203,7 +230,18 @@ constexpr int H_URGENT = 32;               // != 0: a wave of round r needs its 
 constexpr int H_CNT = 48;                  // 16 words per round: match count of each compute wave
 constexpr int H_WBASE = H_CNT + RING * 16; // 32 words per round: {lo, hi} first record index of each compute wave
 constexpr int H_OVF = H_WBASE + RING * 32;  // tiles of this workgroup with more matches than sparse_cap
+constexpr int H_EXIT = H_OVF + 1;          // waves of this workgroup that have left the kernel
 constexpr int H_WORDS = H_OVF + 8;
+
+// Error channel: flags are OR-ed into the control header in DEVICE memory (ordinary device atomics; the last
+// workgroup to leave copies them to the host-mapped result words with plain stores).
+struct ErrCh {
+    unsigned *word;
+    unsigned spin_max;
+};
+__device__ __forceinline__ void err_set(const ErrCh &e, unsigned code) {
+    __hip_atomic_fetch_or(e.word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ unsigned lds_load(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -212,10 +250,10 @@ __device__ __forceinline__ void lds_store(unsigned *p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // Spin (bounded) until *p == want.  Wave-uniform: every lane reads the same word.
-__device__ __forceinline__ bool lds_wait_eq(const unsigned *p, unsigned want, unsigned *err, unsigned code) {
+__device__ __forceinline__ bool lds_wait_eq(const unsigned *p, unsigned want, const ErrCh &err, unsigned code) {
     unsigned spins = 0;
     while (lds_load(p) != want) {
-        if (++spins >= SPIN_MAX) { atomicOr(err, code); return false; }
+        if (++spins >= err.spin_max) { err_set(err, code); return false; }
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -245,9 +283,9 @@ __device__ __forceinline__ void publish_aggregate(unsigned long long *status, un
 // 4 x 64 predecessors are fetched at once (one memory round trip), and the scan stops at the nearest
 // predecessor that already knows its inclusive prefix -- only predecessors nearer than that one have
 // to be published before this batch can finish.  Every spin is bounded: on timeout the error word is
-// set and the kernel still terminates.  Batches are handed out in order and an aggregate is
-// published without waiting for anything, so every predecessor polled here belongs to a workgroup
-// that is running or done.
+// set and the kernel still terminates.  An aggregate is published without waiting for anything, so a predecessor
+// polled here belongs to a workgroup that is running or done -- or has not been drawn yet by its residue class
+// (see TICKET_WAYS), in which case the poll lasts until a workgroup of that class draws it.
 // Window widths (in waves = 64 predecessors each): the window the coordinator loads ahead of time (PRE) and the
 // windows the loop loads when that one did not reach an inclusive prefix (LOOP).  Narrow is better than wide: all
 // workgroups read the same few cache lines of look-back words while their owners write them, and the wider the
@@ -279,7 +317,7 @@ __device__ __forceinline__ void lookback_issue(unsigned long long *status, unsig
 }
 // pre != nullptr: the first window was loaded earlier by lookback_issue().
 __device__ unsigned long long lookback(unsigned long long *status, unsigned tile, unsigned long long tot, int lane,
-                                       unsigned *err, const LbWindow *pre = nullptr) {
+                                       const ErrCh &err, const LbWindow *pre = nullptr, bool publish = true) {
     if (tile == 0) return 0;
     unsigned long long excl = 0;
     long long top = (long long)tile - 1;              // nearest predecessor not yet accounted for
@@ -312,7 +350,7 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
         }
         const int upto = pi < pz ? pi : pz - 1;       // positions 0..upto are usable now (all published)
         if (pi >= pz && pz == 0) {                    // the nearest one is not published yet: poll again
-            if (++spins >= SPIN_MAX) { failed = true; break; }
+            if (++spins >= err.spin_max) { failed = true; break; }
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
@@ -325,10 +363,10 @@ __device__ unsigned long long lookback(unsigned long long *status, unsigned tile
         top -= upto + 1;                              // consumed the published aggregates; continue behind them
     }
     if (failed) {
-        if (lane == 0) atomicOr(err, 1u);
+        if (lane == 0) err_set(err, 1u);
         excl = 0;
     }
-    if (lane == 0) st_store(&status[(long long)tile * ST_STRIDE], ST_INCL | ((excl + tot) & ST_VAL));
+    if (lane == 0 && publish) st_store(&status[(long long)tile * ST_STRIDE], ST_INCL | ((excl + tot) & ST_VAL));
     return excl;
 }
 
@@ -372,10 +410,13 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 //    costs a second, serial walk (walk_store).
 //  * ROOT == 1 (one byte leads out of the root): every survivor's first state is the same one and the dense row is
 //    row 0, so the root-row and row-index lookups -- two dependent LDS round trips per round -- disappear.
+//  * deepf[w] == false (a SHALLOW-FINAL survivor, see the level-2 filter): the walk accounts for its depth-1 state
+//    and stops there.
 template <bool W8, int NWALK, bool FUSED, int MREG, int ROOT>
 __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, int root_state, const unsigned char *d1idx,
                                       const int *D1, bool dense1, const int *D1R2, const int *S0R, const int *R, const int2 *T, const int4 *T4,
-                                      const unsigned (&pos)[NWALK], const bool (&active)[NWALK], unsigned lim, int wbit,
+                                      const unsigned (&pos)[NWALK], const bool (&active)[NWALK], const bool (&deepf)[NWALK],
+                                      unsigned lim, int wbit,
                                       int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
     static_assert(MREG == 2 || MREG == 4, "two or four final states per walk in registers");
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
@@ -416,7 +457,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
                 for (int k = 0; k < MREG; k++) m[w][k] = (fin && n[w] == (unsigned)k) ? (unsigned)s[w] : m[w][k];
             }
             n[w] += fin ? 1u : 0u;
-            go[w] = s[w] >= 0 && p[w] < lim;
+            go[w] = s[w] >= 0 && p[w] < lim && deepf[w];
             any = any || go[w];
         }
         return __any(any);
@@ -543,41 +584,42 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     }
 }
 
+// One record into the global array (the DIRECT paths): a packed word or a wide record.
+__device__ __forceinline__ void put_record(const ScanArgs &a, unsigned long long ri, unsigned tpos, unsigned gpos, unsigned state) {
+    if (ri >= a.out_cap) return;
+    if (a.packed) {
+        static_cast<unsigned *>(a.out)[ri] = tpos | (state << 12);
+    } else {
+        pfac_record rec;
+        rec.pos = gpos;
+        rec.state = state;
+        static_cast<pfac_record *>(a.out)[ri] = rec;
+    }
+}
+
 // Same walk for the rare offsets where more than two patterns start: every final state from the
 // SECOND on goes to the LDS staging buffer (packed) or straight to global memory (the fast walk keeps
 // only the first and the latest final state).
 template <bool W8, bool DIRECT>
-__device__ __forceinline__ void walk_store(const unsigned char *tile, const int *s0, const int *R, const int2 *T,
-                                           unsigned pos, unsigned lim, int wbit, int ht_size, int num_final,
-                                           unsigned *stage, unsigned stage_cap, pfac_record *out,
-                                           unsigned long long out_cap, unsigned long long ri, unsigned gpos) {
+__device__ __forceinline__ void walk_store(const ScanArgs &a, const unsigned char *tile, const int *s0, const int *R, const int2 *T,
+                                           unsigned pos, unsigned lim, unsigned *stage, unsigned long long ri, unsigned gpos) {
     unsigned n = 0;
     int s = s0[tile[pos]];
     unsigned p = pos + 1;
     while (s >= 0) {
-        if (s < num_final) {
+        if (s < a.num_final) {
             if (n >= 1) {                                      // record 0 (m0) is written by the caller
-                if (DIRECT) {
-                    if (ri + n < out_cap) {
-                        pfac_record rec;
-                        rec.pos = gpos;
-                        rec.state = (unsigned)s;
-                        out[ri + n] = rec;
-                    }
-                } else if (ri + n < stage_cap) {
-                    stage[ri + n] = pos | ((unsigned)s << 12);
-                }
+                if (DIRECT) put_record(a, ri + n, pos, gpos, (unsigned)s);
+                else if (ri + n < a.stage_cap) stage[ri + n] = pos | ((unsigned)s << 12);
             }
             n++;
         }
         if (p >= lim) break;
-        s = phf_step<W8>(R, T, s, tile[p], wbit, ht_size);
+        s = phf_step<W8>(R, T, s, tile[p], a.wbit, a.ht_size);
         p++;
     }
 }
 
-// One round: up to 64 survivors (one per lane, in position order) are walked; their records are
-// appended at index `wrun` of the staging buffer (DIRECT == false) or of the global record array.
 struct Dense1 {
     const unsigned char *idx;
     const int *rows;
@@ -586,9 +628,10 @@ struct Dense1 {
     const int *s0r;     // no dense rows (FUSED): r[] of the depth-1 state each root byte leads to, in LDS; else null
 };
 
-// One round: up to 64*NWALK survivors -- queue entries [q0, q0+nact), lane L takes entries L, L+64, ... walked
-// side by side -- append their records, in queue (= position) order, at index `wrun` of the staging
-// buffer (DIRECT == false) or of the global record array.  Returns the number of records.
+// One round: up to 64*NWALK FIFO entries [q0, q0+nact), lane L takes entries L, L+64, ... side by side; their records
+// are appended, in queue (= position) order, at index `wrun` of the staging buffer (DIRECT == false) or of the global
+// record array.  Entries without QDEEP are shallow-final survivors: one record, the depth-1 state of their byte; a
+// round made of those alone needs neither a walk nor a prefix sum.  Returns the number of records.
 template <bool W8, bool DIRECT, int NWALK, bool FUSED, int ROOT>
 __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
                                            const int *R, const int2 *T, const unsigned short *q, unsigned q0,
@@ -596,14 +639,29 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
                                            unsigned long long tile_base, unsigned long long wrun) {
     static_assert(NWALK == 1 || NWALK == 2 || NWALK == 4, "one, two or four walks per lane");
     constexpr int MREG = NWALK == 4 ? 4 : 2;
-    bool active[NWALK];
+    bool active[NWALK], deepf[NWALK];
     unsigned pos[NWALK], n[NWALK], m[NWALK][MREG];
+    bool anydeep = false;
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
         active[w] = (unsigned)lane + WAVE * w < nact;
-        pos[w] = active[w] ? q[q0 + WAVE * w + lane] : 0u;
+        const unsigned e = active[w] ? q[q0 + WAVE * w + lane] : 0u;
+        pos[w] = e & 0xFFFu;
+        deepf[w] = (e & QDEEP) != 0;
+        anydeep = anydeep || deepf[w];
     }
-    walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, lim,
+    if (!__any(anydeep)) {
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) {
+            if (!active[w]) continue;
+            const unsigned st = ROOT == 1 ? (unsigned)a.root_state : (unsigned)s0[tile[pos[w]]];
+            const unsigned long long ri = wrun + WAVE * w + lane;
+            if (DIRECT) put_record(a, ri, pos[w], (unsigned)tile_base + pos[w], st);
+            else if (ri < a.stage_cap) stage[ri] = pos[w] | (st << 12);
+        }
+        return nact;
+    }
+    walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, deepf, lim,
                                         a.wbit, a.ht_size, a.num_final, n, m);
     // prefix sums of the counts, two walks per scan (16-bit fields; a walk reports < 1024 matches)
     unsigned ex[NWALK], total = 0;
@@ -624,53 +682,71 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
         const bool regs = n[w] <= (unsigned)MREG;              // every record of this walk is in registers
+        const unsigned gpos = (unsigned)tile_base + pos[w];
         if (DIRECT) {
             const unsigned long long ri = wrun + ex[w];
-            pfac_record rec;
-            rec.pos = (unsigned)(tile_base + pos[w]);
-            if (n[w] > 0 && ri < a.out_cap) { rec.state = m[w][0]; a.out[ri] = rec; }
+            if (n[w] > 0) put_record(a, ri, pos[w], gpos, m[w][0]);
 #pragma unroll
             for (int k = 1; k < MREG; k++)
-                if (regs && n[w] > (unsigned)k && ri + k < a.out_cap) { rec.state = m[w][k]; a.out[ri + k] = rec; }
-            if (!regs)
-                walk_store<W8, true>(tile, s0, R, T, pos[w], lim, a.wbit, a.ht_size, a.num_final, nullptr, 0, a.out, a.out_cap, ri, rec.pos);
+                if (regs && n[w] > (unsigned)k) put_record(a, ri + k, pos[w], gpos, m[w][k]);
+            if (!regs) walk_store<W8, true>(a, tile, s0, R, T, pos[w], lim, nullptr, ri, gpos);
         } else {
             const unsigned ri = (unsigned)wrun + ex[w];        // tile-local record index: 32 bits are plenty
             if (n[w] > 0 && ri < a.stage_cap) stage[ri] = pos[w] | (m[w][0] << 12);
 #pragma unroll
             for (int k = 1; k < MREG; k++)
                 if (regs && n[w] > (unsigned)k && ri + k < a.stage_cap) stage[ri + k] = pos[w] | (m[w][k] << 12);
-            if (!regs)
-                walk_store<W8, false>(tile, s0, R, T, pos[w], lim, a.wbit, a.ht_size, a.num_final, stage, a.stage_cap, nullptr, 0, ri, 0);
+            if (!regs) walk_store<W8, false>(a, tile, s0, R, T, pos[w], lim, stage, ri, 0);
         }
     }
     return total;
 }
 
-// Compaction + walk over one wave tile.  Survivors (set bits of the per-lane masks) are appended,
-// in position order, to a FIFO in LDS; whenever 64 are pending a full round runs, so lanes stay
-// busy even when only one offset in thirteen survives the root test.  Returns the tile's match
-// count; with DIRECT the records are written at global index wrun onwards.
+// Compaction + walk over one wave tile.  keep[j] = the survivors of half-tile j that yield a record or need a walk
+// (bit b = byte b of the lane's 32), deep[j] = those of them that need the walk.  Kept survivors are appended, in
+// position order, to a FIFO in LDS; whenever 64 are pending a full round runs, so lanes stay busy even when only
+// one offset in thirteen survives the root test.  Returns the tile's match count; with DIRECT the records are
+// written at global index wrun onwards.
 template <bool W8, bool DIRECT, int NWALK, bool FUSED, int ROOT>
 __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const unsigned char *tile, const int *s0,
                                                         const Dense1 &d1, const int *R, const int2 *T, unsigned short *q,
-                                                        unsigned *stage, const unsigned (&masks)[MSUBS], int lane,
+                                                        unsigned *stage, const unsigned (&keep)[MSUBS],
+                                                        const unsigned (&deep)[MSUBS], int lane,
                                                         unsigned lim, unsigned long long tile_base,
                                                         unsigned long long wrun) {
     unsigned tail = 0;                         // pending survivors, always < one round between appends
     // per-lane survivor counts of the 2 half-tiles, prefix-summed in one packed DPP scan (16-bit fields: a
     // half-tile holds at most 2048 survivors)
     static_assert(MSUBS == 2, "the packed scan assumes 2 half-tiles");
-    const unsigned c0 = __popc(masks[0]), c1 = __popc(masks[1]);
+    const unsigned c0 = __popc(keep[0]), c1 = __popc(keep[1]);
     const unsigned pa = wave_incl_scan(c0 | (c1 << 16));
     const unsigned incls[MSUBS] = {pa & 0xFFFFu, pa >> 16};
     const unsigned cnts[MSUBS] = {c0, c1};
     const unsigned la = bcast_last(pa);
     const unsigned totals[MSUBS] = {la & 0xFFFFu, la >> 16};
+    if (ROOT == 1 && !__any((deep[0] | deep[1]) != 0u)) {
+        // No deep survivor in the tile (the usual case for a sparse pattern set): every kept survivor is exactly one
+        // record, the depth-1 state -- written straight to its slot, in position order; no FIFO, no rounds.
+        const unsigned st = (unsigned)a.root_state;
+#pragma unroll
+        for (int j = 0; j < MSUBS; j++) {
+            if (totals[j] == 0) continue;
+            const unsigned lpos = j * MSUB + lane * MLANE;
+            unsigned o = (j ? totals[0] : 0u) + incls[j] - cnts[j];
+            for (unsigned m = keep[j]; m; m &= m - 1) {
+                const unsigned pos = lpos + (__ffs(m) - 1);
+                if (DIRECT) put_record(a, wrun + o, pos, (unsigned)tile_base + pos, st);
+                else if (o < a.stage_cap) stage[o] = pos | (st << 12);
+                o++;
+            }
+        }
+        return wrun + totals[0] + totals[1];
+    }
     constexpr unsigned RW = WAVE * NWALK;      // survivors per round
 #pragma unroll
     for (int j = 0; j < MSUBS; j++) {
-        const unsigned mask = masks[j];
+        const unsigned mask = keep[j];
+        const unsigned dmask = deep[j];
         const unsigned cnt = cnts[j];
         const unsigned incl = incls[j];
         const unsigned S = totals[j];
@@ -689,7 +765,10 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             }
             if (mine) {
                 unsigned o = tail + (incl - cnt) - gbase;
-                for (unsigned m = mask; m; m &= m - 1) q[o++] = (unsigned short)(lpos + (__ffs(m) - 1));
+                for (unsigned m = mask; m; m &= m - 1) {
+                    const unsigned b = __ffs(m) - 1;
+                    q[o++] = (unsigned short)((lpos + b) | (((dmask >> b) & 1u) << 15));
+                }
             }
             tail += gcnt;
             wave_lds_sync();
@@ -713,43 +792,28 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
     return wrun;
 }
 
-// Staged records of one tile -> global memory, in order.  Two records (16 bytes) per lane per store:
-// 8-byte-per-lane stores are issue-bound on CDNA (half the bytes per instruction).
-__device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base,
-                                         unsigned long long tile_base, int lane) {
+// Staged words of one tile -> global memory, in order (packed format only: the staged word IS the record).  Four
+// records (16 bytes) per lane per store, aligned to the record array.
+__device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base, int lane) {
     if (cnt == 0) return;
-    const unsigned tb = (unsigned)tile_base;                   // tile_base is a multiple of 4096
-    const unsigned head = (unsigned)(base & 1ull);             // odd first index: one single record keeps pairs 16-B aligned
-    if (head && lane == 0 && base < a.out_cap) {
-        const unsigned v = stage[0];
-        pfac_record rec;
-        rec.pos = tb | (v & 0xFFFu);
-        rec.state = v >> 12;
-        a.out[base] = rec;
+    unsigned *out = static_cast<unsigned *>(a.out);
+    if (base + cnt > a.out_cap) {              // the record array ends inside this tile: word by word, checked
+        for (unsigned i = (unsigned)lane; i < cnt; i += WAVE)
+            if (base + i < a.out_cap) out[base + i] = stage[i];
+        return;
     }
-    unsigned i = head + 2u * (unsigned)lane;
-    // the usual case, four records per lane per trip: both LDS reads are in flight before either pair is stored
-    // (wave-uniform condition: everything up to the end of this trip exists and fits)
-    while (i - 2u * (unsigned)lane + 4u * WAVE <= cnt && base + cnt <= a.out_cap) {
-        const unsigned a0 = stage[i], a1 = stage[i + 1], b0 = stage[i + 2u * WAVE], b1 = stage[i + 2u * WAVE + 1];
-        u32x4 pa = {tb | (a0 & 0xFFFu), a0 >> 12, tb | (a1 & 0xFFFu), a1 >> 12};
-        u32x4 pb = {tb | (b0 & 0xFFFu), b0 >> 12, tb | (b1 & 0xFFFu), b1 >> 12};
-        *reinterpret_cast<u32x4 *>(&a.out[base + i]) = pa;
-        *reinterpret_cast<u32x4 *>(&a.out[base + i + 2u * WAVE]) = pb;
-        i += 4u * WAVE;
+    unsigned head = (0u - (unsigned)base) & 3u;                // records up to the next 16-byte boundary of the array
+    head = head < cnt ? head : cnt;
+    if ((unsigned)lane < head) out[base + lane] = stage[lane];
+    unsigned i = head + 4u * (unsigned)lane;
+    for (; i + 4u <= cnt; i += 4u * WAVE) {
+        const u32x4 v = {stage[i], stage[i + 1], stage[i + 2], stage[i + 3]};
+        *reinterpret_cast<u32x4 *>(out + base + i) = v;
     }
-    for (; i < cnt; i += 2u * WAVE) {
-        const unsigned v0 = stage[i];
-        if (i + 1 < cnt && base + i + 1 < a.out_cap) {
-            const unsigned v1 = stage[i + 1];
-            u32x4 two = {tb | (v0 & 0xFFFu), v0 >> 12, tb | (v1 & 0xFFFu), v1 >> 12};
-            *reinterpret_cast<u32x4 *>(&a.out[base + i]) = two;
-        } else if (base + i < a.out_cap) {
-            pfac_record rec;
-            rec.pos = tb | (v0 & 0xFFFu);
-            rec.state = v0 >> 12;
-            a.out[base + i] = rec;
-        }
+    if (i < cnt) {                             // the last 1..3 records (one lane)
+        out[base + i] = stage[i];
+        if (i + 1 < cnt) out[base + i + 1] = stage[i + 1];
+        if (i + 2 < cnt) out[base + i + 2] = stage[i + 2];
     }
 }
 
@@ -783,24 +847,33 @@ __device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned char
     }
 }
 
+// Bytes equal to x (replicated x4) among the lane's 32: bit b <=> byte b.
+__device__ __forceinline__ unsigned eq_mask32(const u32x4 lo16, const u32x4 hi16, unsigned x4) {
+    return root_mask<1>(lo16, nullptr, x4) | (root_mask<1>(hi16, nullptr, x4) << 16);
+}
+
+#ifdef PFAC_TRACE_BUILD
+#define PFAC_STAMP(cond, slot) do { if (cond) tr[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PFAC_STAMP(cond, slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // The scan kernel.  Workgroups share the read-only tables staged in LDS once; after that there is
 // no workgroup barrier: compute waves pipeline  [loads of round r+1 in flight | scan round r |
-// emit round r-1]  and meet the coordinator only through the LDS rings above.
+// emit round r-2]  and meet the coordinator only through the LDS rings above.
 constexpr int MAX_WAVES_NW4 = 10;          // four walks per lane need registers: at most 10 waves per workgroup (dense mode has 9-10)
+
 template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW>
-__global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLOCK)) void pfac_scan_kernel(ScanArgs a) {
-    static_assert(!(TLDS && FUSED), "the fused table is for tables gathered through L2");
-    static_assert(NW == (TLDS ? 1 : 2) || (FUSED && NW == 4), "walks per lane: 1 (LDS tables), 2 (L2 tables), 4 (L2, fused, dense matches)");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem, const ErrCh &err) {
     unsigned *hdr = reinterpret_cast<unsigned *>(smem + SH_HDR);
     int *s0 = reinterpret_cast<int *>(smem + SH_S0);
     unsigned char *ftab = smem + SH_FTAB;
+    unsigned char *finl = smem + SH_FIN;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int nc = (int)(blockDim.x >> 6) - 1;             // compute waves; wave nc coordinates
-    unsigned *err = &a.res[2];             // error paths only: an atomic on host memory is fine there
 
     // ---- the control words of the slot's NEXT scan (ticket + look-back words of its other buffer) are zeroed here,
     // spread over the whole grid: the next launch on the stream starts after this one has ended
@@ -811,6 +884,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     for (int i = tid; i < 256; i += blockDim.x) {
         const int v = a.s0[i];
         s0[i] = v;
+        finl[i] = (unsigned)v < (unsigned)a.num_final ? (unsigned char)1 : (unsigned char)0;
 #pragma unroll
         for (int k = 0; k < 8; k++) ftab[k * 256 + i] = v >= 0 ? (unsigned char)(1u << k) : (unsigned char)0;
     }
@@ -845,6 +919,13 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         R = lr;
         T = lt;
     }
+    // level-2 filter, lookup form: the 2-byte-prefix bitmap (all 256 rows, or the root byte's row when ROOT == 1)
+    const unsigned char *bm2l = smem + a.sh_bm2;
+    if (a.l2f_mode == 2) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(a.bm2 + (ROOT == 1 ? (a.root_byte & 0xFFu) * 32u : 0u));
+        unsigned *dst = reinterpret_cast<unsigned *>(smem + a.sh_bm2);
+        for (int i = tid; i < a.bm2_rows * 8; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();                           // the only workgroup barrier
 
     if (wave == nc) {
@@ -877,13 +958,14 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         // Rounds in flight in the coordinator: round r (waiting for its counts), round r-1 (aggregate
         // published, look-back window loads just issued) and round r-2 (window loads issued one round
         // ago -> finished from registers now).
-        struct Pend { bool on; unsigned r, g; unsigned long long tot, end; unsigned cnt; };
-        Pend p1 = {false, 0, 0, 0, 0, 0}, p2 = {false, 0, 0, 0, 0, 0};
+        struct Pend { bool on; unsigned r, g; unsigned long long tot, first, end; unsigned cnt; bool mute; };
+        Pend p1 = {false, 0, 0, 0, 0, 0, 0, false}, p2 = {false, 0, 0, 0, 0, 0, 0, false};
         LbWindow win = {};
         unsigned long long t_pub = 0;          // when this workgroup's last aggregate went out (100 MHz ticks)
-        // resolve a round: batch base from the look-back, then every compute wave's first record index
+        // resolve a round: batch base from the look-back, then every compute wave's first record index -- to LDS for
+        // the waves and, as the tiles' first-record indices, to the tile index of the record array
         auto resolve = [&](const Pend &p, const LbWindow *pre) {
-            const unsigned long long excl = lookback(a.status, p.g, p.tot, lane, err, pre);
+            const unsigned long long excl = lookback(a.status, p.g, p.tot, lane, err, pre, !p.mute);
             // exclusive prefix of the waves' counts (lane c holds wave c's count)
             const unsigned incl = wave_incl_scan(p.cnt);
             const unsigned long long wb = excl + (incl - p.cnt);
@@ -892,12 +974,12 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
                 hdr[H_WBASE + (p.r & 7) * 32 + lane * 2 + 1] = (unsigned)(wb >> 32);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) {
-                lds_store(&hdr[H_READY + (p.r & 7)], p.r + 1);
-                if (p.end >= a.n_tiles) {                   // this batch holds the last tile: grand total
-                    a.res[0] = (unsigned)(excl + p.tot);
-                    a.res[1] = (unsigned)((excl + p.tot) >> 32);
-                }
+            if (lane == 0) lds_store(&hdr[H_READY + (p.r & 7)], p.r + 1);
+            if (p.first + (unsigned)lane < p.end) a.tile_first[p.first + (unsigned)lane] = wb;
+            if (lane == 0 && p.end >= a.n_tiles) {             // this batch holds the last tile: grand total
+                a.tile_first[a.n_tiles] = excl + p.tot;
+                a.res[0] = (unsigned)(excl + p.tot);
+                a.res[1] = (unsigned)((excl + p.tot) >> 32);
             }
         };
         for (unsigned r = 0;; r++) {
@@ -905,15 +987,17 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
             if (first >= a.n_tiles) break;     // batches are handed out in order: nothing left for this workgroup
             const unsigned g_nxt2 = publish_batch(r + 2, t_pending);   // two rounds ahead of the compute waves
             t_pending = ticket();                           // for round r+3
+#ifdef PFAC_TRACE_BUILD
             const bool trace = a.dbg && blockIdx.x < 8 && r < 64 && lane == 0;
-            unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + r) * 32;
-            if (trace) tr[0] = __builtin_amdgcn_s_memrealtime();
+            unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + (r & 63)) * 32;
+#endif
+            PFAC_STAMP(trace, 0);
             // (a) round r-2: its window loads were issued a whole round ago
             if (p2.on) { resolve(p2, &win); p2.on = false; }
             // (b) round r: wait for the counts, publish the aggregate
             const unsigned long long left = a.n_tiles - first;
             const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
-            // While waiting: once round r-1's aggregate has been out for lb_trigger ticks (3.8 us: time for the
+            // While waiting: once round r-1's aggregate has been out for lb_trigger ticks (3.0 us: time for the
             // workgroups ahead of this one to have resolved THEIR round r-1, so the window ends at an inclusive prefix),
             // start loading its look-back window -- the memory round trip then overlaps the rest of the arrivals
             // instead of sitting in front of the next iteration.  Short rounds (sparse input) never get there and load
@@ -927,7 +1011,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
                 if (!win_issued) {
                     unsigned arr = lds_load(&hdr[H_ARRIVED + (r & 7)]);
                     while (arr != n_valid && __builtin_amdgcn_s_memrealtime() - t_pub < (unsigned long long)a.lb_trigger) {
-                        if (++spins >= SPIN_MAX) { atomicOr(err, 4u); failed = true; break; }
+                        if (++spins >= err.spin_max) { err_set(err, 4u); failed = true; break; }
                         __builtin_amdgcn_s_sleep(1);
                         arr = lds_load(&hdr[H_ARRIVED + (r & 7)]);
                     }
@@ -935,12 +1019,13 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
                 }
                 if (failed || !lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
             }
-            if (trace) tr[1] = __builtin_amdgcn_s_memrealtime();
+            PFAC_STAMP(trace, 1);
             const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
             const unsigned long long tot = bcast_last(wave_incl_scan(c));   // 15 tile counts of < 2^22 each
-            publish_aggregate(a.status, g_cur, tot, lane);
+            const bool mute = (a.fault & 1u) && blockIdx.x == 1 && r == 1;   // test knob: this batch is never published
+            if (!mute) publish_aggregate(a.status, g_cur, tot, lane);
             t_pub = __builtin_amdgcn_s_memrealtime();
-            const Pend cur = {true, r, g_cur, tot, first + n_valid, c};
+            const Pend cur = {true, r, g_cur, tot, first, first + n_valid, c, mute};
             // (c) round r-1 moves on: issue its look-back window now, finish it next iteration
             if (p1.on) { if (!win_issued) lookback_issue(a.status, p1.g, lane, win); p2 = p1; p1.on = false; }
             p1 = cur;
@@ -949,7 +1034,9 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
                 resolve(p1, nullptr);
                 p1.on = false;
             }
+#ifdef PFAC_TRACE_BUILD
             if (trace) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = g_cur; }
+#endif
             g_cur = g_nxt;
             g_nxt = g_nxt2;
         }
@@ -957,7 +1044,10 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         if (p1.on) resolve(p1, nullptr);
         // every count of this workgroup has been posted by now: report how many tiles were denser than the sparse
         // staging capacity (the host switches staging mode on it)
-        if (lane == 0) { const unsigned ovf = lds_load(&hdr[H_OVF]); if (ovf) atomicAdd(&a.res[3], ovf); }
+        if (lane == 0) {
+            const unsigned ovf = lds_load(&hdr[H_OVF]);
+            if (ovf) __hip_atomic_fetch_add(&a.ctl[CTL_OVF], ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
 
@@ -965,6 +1055,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     unsigned char *tile = smem + a.shared_bytes + wave * a.pw_bytes;
     unsigned short *q = reinterpret_cast<unsigned short *>(tile + WTILE + a.halo);
     unsigned *stage0 = reinterpret_cast<unsigned *>(tile + WTILE + a.halo + QCAP * 2);
+    const bool root_final = ROOT == 1 && (unsigned)a.root_state < (unsigned)a.num_final;
 
     // prefetch registers: the wave's 4 KiB + halo
     u32x4 w[SUBS];
@@ -1001,16 +1092,17 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     // pending[k]: the tile scanned k+1 rounds ago still sits in its staging buffer
     bool have1 = false, have2 = false;
     unsigned cnt1 = 0, cnt2 = 0, buf = 0;      // buf: staging buffer of the current round, (r % NBUF)
-    unsigned long long t1 = 0, t2 = 0;
 
     for (;;) {
         const unsigned long long tile_base = t * WTILE;
         const unsigned long long remain = a.n_avail - tile_base;           // > 0
         const unsigned lim = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
 
+#ifdef PFAC_TRACE_BUILD
         const bool trace = a.dbg && blockIdx.x < 8 && r < 64 && lane == 0 && wave == 0;
-        unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + r) * 32;
-        if (trace) tr[4] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + (r & 63)) * 32;
+#endif
+        PFAC_STAMP(trace, 4);
         // ---- registers -> LDS (tile + halo), then start the next round's loads right away
 #pragma unroll
         for (int j = 0; j < SUBS; j++) *reinterpret_cast<u32x4 *>(tile + j * SUB + lane * 16) = w[j];
@@ -1020,7 +1112,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
             if (lane < (int)(lim & 15u)) tile[(lim & ~15u) + lane] = a.in[tile_base + (lim & ~15u) + lane];
         }
         wave_lds_sync();
-        if (trace) tr[5] = __builtin_amdgcn_s_memrealtime();
+        PFAC_STAMP(trace, 5);
         bool more = lds_wait_eq(&hdr[H_EPOCH + ((r + 1) & 7)], r + 2, err, 16u);
         unsigned long long t_next = 0;
         if (more) {
@@ -1029,29 +1121,69 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         }
         if (more) issue_loads(t_next);
 
-        // ---- root test -> 16-bit survivor mask per lane per sub-tile
-        unsigned masks[MSUBS];
+        // ---- root test -> 32-bit survivor mask per lane per half-tile; level-2 filter -> which of them are kept
+        // (yield a record or need a walk) and which of those are deep (need the walk)
+        unsigned keep[MSUBS], deep[MSUBS];
 #pragma unroll
         for (int j = 0; j < MSUBS; j++) {
             const unsigned off = j * MSUB + lane * MLANE;
             const u32x4 lo16 = *reinterpret_cast<const u32x4 *>(tile + off);
             const u32x4 hi16 = *reinterpret_cast<const u32x4 *>(tile + off + 16);
-            masks[j] = root_mask<ROOT>(lo16, ftab, a.root_byte) | (root_mask<ROOT>(hi16, ftab, a.root_byte) << 16);
-        }
-        if (tile_base + WTILE > a.n_owned) {   // last tile only: offsets at or past n_owned start no walk
-#pragma unroll
-            for (int j = 0; j < MSUBS; j++) {
-                const unsigned long long g = tile_base + j * MSUB + lane * MLANE;
-                if (g + MLANE > a.n_owned) masks[j] = g >= a.n_owned ? 0u : (masks[j] & ((1u << (unsigned)(a.n_owned - g)) - 1u));
+            const unsigned raw = root_mask<ROOT>(lo16, ftab, a.root_byte) | (root_mask<ROOT>(hi16, ftab, a.root_byte) << 16);
+            unsigned m1 = raw;
+            if (tile_base + WTILE > a.n_owned) {   // last tile only: offsets at or past n_owned start no walk
+                const unsigned long long g = tile_base + off;
+                if (g + MLANE > a.n_owned) m1 = g >= a.n_owned ? 0u : (m1 & ((1u << (unsigned)(a.n_owned - g)) - 1u));
+            }
+            if (a.l2f_mode == 0) {
+                keep[j] = m1;
+                deep[j] = m1;
+            } else if (ROOT == 1 && a.l2f_mode == 1) {
+                // bit-parallel: deep <=> the NEXT byte is a child byte of the depth-1 state (byte 32 = the first byte of
+                // the next lane's run, or of the halo)
+                unsigned nextc = 0;
+                if (a.n_child > 0) {
+                    const unsigned nx = *reinterpret_cast<const unsigned *>(tile + off + 32);
+                    unsigned ec = a.child0 == a.root_byte ? raw : eq_mask32(lo16, hi16, a.child0);
+                    unsigned e32 = ((nx ^ a.child0) & 0xFFu) == 0u ? 1u : 0u;
+                    if (a.n_child > 1) {
+                        ec |= a.child1 == a.root_byte ? raw : eq_mask32(lo16, hi16, a.child1);
+                        e32 |= ((nx ^ a.child1) & 0xFFu) == 0u ? 1u : 0u;
+                    }
+                    nextc = (ec >> 1) | (e32 << 31);
+                }
+                deep[j] = m1 & nextc;
+                keep[j] = root_final ? m1 : deep[j];
+            } else {
+                // one lookup per survivor in the 2-byte-prefix bitmap (and, for a multi-edge root, in the
+                // depth-1-state-is-final table)
+                unsigned dm = 0, fm = 0;
+                for (unsigned mm = m1; mm; mm &= mm - 1) {
+                    const unsigned b = __ffs(mm) - 1;
+                    const unsigned b1 = tile[off + b + 1];
+                    unsigned row = 0, fin = 0;
+                    if (ROOT != 1) {
+                        const unsigned b0 = tile[off + b];
+                        row = b0 * 32u;
+                        fin = finl[b0];
+                    }
+                    const unsigned v = bm2l[row + (b1 >> 3)];
+                    dm |= ((v >> (b1 & 7u)) & 1u) << b;
+                    fm |= fin << b;
+                }
+                deep[j] = dm;
+                keep[j] = dm | (ROOT == 1 ? (root_final ? m1 : 0u) : fm);
             }
         }
 
-        if (trace) tr[6] = __builtin_amdgcn_s_memrealtime();
+        PFAC_STAMP(trace, 6);
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * a.stage_cap;
-        const unsigned long long cnt = tile_pass<W8, false, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, 0);
-        if (trace) tr[7] = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long cnt = tile_pass<W8, false, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, 0);
+        PFAC_STAMP(trace, 7);
+#ifdef PFAC_TRACE_BUILD
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
         const bool overflow = cnt > a.stage_cap;
         const bool now = overflow || a.nbuf == 1;          // this tile is emitted right away (needs its base at once)
         unsigned arrival = 0;
@@ -1068,40 +1200,65 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         if (__builtin_amdgcn_readfirstlane(arrival) * 2u >= (unsigned)nc) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
 
-        if (now) {
+        if (now && cnt != 0) {
             unsigned long long base = 0;
             if (record_base(r, base)) {
                 if (overflow)
                     // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
                     // while its bytes are still in LDS, writing straight to global memory
-                    tile_pass<W8, true, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, masks, lane, lim, tile_base, base);
+                    tile_pass<W8, true, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, base);
                 else
-                    copy_out(a, stage, (unsigned)cnt, base, tile_base, lane);   // dense mode: staged, emitted at once
+                    copy_out(a, stage, (unsigned)cnt, base, lane);   // dense mode: staged, emitted at once
             }
         }
-        // ---- emit the tile of TWO rounds ago: its batch base has long been resolved
-        if (have2) {
+        // ---- emit the tile of TWO rounds ago: its batch base has long been resolved (a tile without records has
+        // nothing to wait for: the coordinator stores the tile index)
+        if (have2 && cnt2 != 0) {
             unsigned long long base = 0;
             const bool okb = record_base(r - 2, base);
-            if (trace) tr[9] = __builtin_amdgcn_s_memrealtime();
-            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, t2 * WTILE, lane);
+            PFAC_STAMP(trace, 9);
+            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, lane);
         }
-        if (trace) tr[8] = __builtin_amdgcn_s_memrealtime();
-        have2 = have1; cnt2 = cnt1; t2 = t1;
-        have1 = !now; cnt1 = (unsigned)cnt; t1 = t;
+        PFAC_STAMP(trace, 8);
+        have2 = have1; cnt2 = cnt1;
+        have1 = !now; cnt1 = (unsigned)cnt;
         buf = a.nbuf == 1 ? 0u : (buf + 1) % NBUF;
         if (!more) break;
         t = t_next;
         r++;
     }
     // drain: the last two rounds' tiles (staged in buffers buf+1 [two rounds ago] and buf+2 [last round])
-    if (have2) {
+    if (have2 && cnt2 != 0) {
         unsigned long long base = 0;
-        if (record_base(r - 1, base)) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, t2 * WTILE, lane);
+        if (record_base(r - 1, base)) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, lane);
     }
-    if (have1) {
+    if (have1 && cnt1 != 0) {
         unsigned long long base = 0;
-        if (record_base(r, base)) copy_out(a, stage0 + ((buf + 2) % NBUF) * a.stage_cap, cnt1, base, t1 * WTILE, lane);
+        if (record_base(r, base)) copy_out(a, stage0 + ((buf + 2) % NBUF) * a.stage_cap, cnt1, base, lane);
+    }
+}
+
+template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW>
+__global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLOCK)) void pfac_scan_kernel(ScanArgs a) {
+    static_assert(!(TLDS && FUSED), "the fused table is for tables gathered through L2");
+    static_assert(NW == (TLDS ? 1 : 2) || (FUSED && NW == 4), "walks per lane: 1 (LDS tables), 2 (L2 tables), 4 (L2, fused, dense matches)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ErrCh err = {&a.ctl[CTL_ERR], a.spin_max};
+    scan_body<TLDS, W8, ROOT, FUSED, NW>(a, smem, err);
+    // ---- leaving: the last wave of the workgroup counts the workgroup out; the last workgroup of the grid copies
+    // the error flags and the dense-tile count from the control header (device memory) to the host-visible result
+    // words with plain stores.  Every wave comes through here, whichever way it left the loop.
+    unsigned *hdr = reinterpret_cast<unsigned *>(smem + SH_HDR);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's flag atomics have been performed
+        const unsigned left = atomicAdd(&hdr[H_EXIT], 1u);
+        if (left + 1 == (blockDim.x >> 6)) {
+            const unsigned done = __hip_atomic_fetch_add(&a.ctl[CTL_DONE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (done + 1 == gridDim.x) {
+                a.res[2] = __hip_atomic_load(&a.ctl[CTL_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.res[3] = __hip_atomic_load(&a.ctl[CTL_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -1165,10 +1322,70 @@ __global__ void pfac_pack_d1_kernel(int *d1, int n_entries, const int *r, int wb
     d1[i] = nx | (k << D1_STATE_BITS);
 }
 
+// 2-byte-prefix bitmap: bit (b0 << 8 | b1) set iff the root has an edge on b0 and that state one on b1 (the level-2
+// filter of the scan).  One block per b0, one thread per b1; a wave's ballot is 8 bytes of the row.
+__global__ void pfac_build_bm2_kernel(const int *s0, const int *r, const int2 *T, int wbit, int ht_size, unsigned long long *bm2) {
+    const int st = s0[blockIdx.x];
+    const int c = threadIdx.x;
+    int nx = -1;
+    if (st >= 0) {
+        const int key = (st << 8) | c;
+        const int row = key >> wbit;
+        const int idx = r[row] + (key & ((1 << wbit) - 1));
+        if ((unsigned)idx < (unsigned)ht_size) {
+            const int2 e = T[idx];
+            if (e.x == row) nx = e.y;
+        }
+    }
+    const unsigned long long bits = __ballot(nx >= 0);
+    if ((c & (WAVE - 1)) == 0) bm2[blockIdx.x * 4 + (c >> 6)] = bits;
+}
+
 __device__ __forceinline__ unsigned long long match_hash(unsigned long long pos, unsigned id) {
     unsigned long long x = (pos + 1) * 0x9E3779B97F4A7C15ull ^ ((unsigned long long)id * 0xC2B2AE3D27D4EB4Full);
     x ^= x >> 29;
     return x * 0xBF58476D1CE4E5B9ull;
+}
+
+// Packed records: one wave per tile at a time; record i of tile t is word i of [tile_first[t], tile_first[t+1]).
+// Only records with index < n count (n <= total).
+__global__ void pfac_checksum_packed_kernel(const unsigned *rec, const unsigned long long *tile_first, unsigned long long n_tiles,
+                                            unsigned long long n, unsigned long long base, const int *idmap,
+                                            unsigned long long *out) {
+    unsigned long long sum = 0;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long wstride = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+    for (unsigned long long t = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < n_tiles; t += wstride) {
+        const unsigned long long lo = tile_first[t];
+        unsigned long long hi = tile_first[t + 1];
+        hi = hi < n ? hi : n;
+        for (unsigned long long i = lo + lane; i < hi; i += WAVE) {
+            const unsigned w = rec[i];
+            sum += match_hash(base + t * WTILE + (w & 0xFFFu), (unsigned)idmap[w >> 12]);
+        }
+    }
+    sum = wave_sum64(sum);
+    if (lane == 0) atomicAdd(out, sum);
+}
+
+// Packed -> wide: records [first, first + n) of the scan as pfac_record {pos relative to the scanned range, state}.
+__global__ void pfac_expand_kernel(const unsigned *rec, const unsigned long long *tile_first, unsigned long long n_tiles,
+                                   unsigned long long first, unsigned long long n, pfac_record *out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long wstride = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+    const unsigned long long end = first + n;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < n_tiles; t += wstride) {
+        unsigned long long lo = tile_first[t], hi = tile_first[t + 1];
+        lo = lo > first ? lo : first;
+        hi = hi < end ? hi : end;
+        for (unsigned long long i = lo + lane; i < hi; i += WAVE) {
+            const unsigned w = rec[i];
+            pfac_record o;
+            o.pos = (unsigned)(t * WTILE) + (w & 0xFFFu);
+            o.state = w >> 12;
+            out[i - first] = o;
+        }
+    }
 }
 
 __global__ void pfac_checksum_kernel(const pfac_record *rec, unsigned long long n, unsigned long long base,
@@ -1224,8 +1441,14 @@ struct Slot {
     hipStream_t stream = nullptr;
     unsigned char *d_input = nullptr;
     uint64_t input_cap = 0;
-    pfac_record *d_records = nullptr;
+    void *d_records = nullptr;            // record_cap x 8 bytes: holds either record format
     uint64_t record_cap = 0;
+    unsigned long long *d_tile_first = nullptr;   // packed scans: first record index of every tile (+ the total)
+    uint64_t tile_cap = 0;
+    pfac_record *d_wide = nullptr;        // scratch of pfac_records_d2h: packed records expanded on the device
+    uint64_t wide_cap = 0;
+    bool last_packed = false;             // record format of the slot's last scan
+    const void *last_records = nullptr;   // ... and where it wrote
     unsigned *d_ctl = nullptr;            // TWO control buffers (16 control words + the status array each), used alternately:
     unsigned *d_ctlbuf[2] = {nullptr, nullptr};   // a scan zeroes the other one for the scan after it
     uint64_t clean[2] = {0, 0};           // status words (from 0) of each buffer known to be zero
@@ -1235,9 +1458,9 @@ struct Slot {
     unsigned *d_res = nullptr;            // device-side address of h_ctl
     unsigned long long *d_sum = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    uint64_t last_cap = 0, last_tiles = 0;
+    uint64_t last_cap = 0, last_tiles = 0, last_total = 0;
     bool scanned = false, pending = false, last_dense = false;
-    unsigned long long *d_dbg = nullptr;  // PFAC_TRACE
+    unsigned long long *d_dbg = nullptr;  // PFAC_TRACE_BUILD + PFAC_TRACE
 };
 
 }  // namespace
@@ -1269,6 +1492,14 @@ struct pfac_ctx {
     int d1_rows = 0;
     int d1_n2 = 0;                        // > 0: dense rows are packed (fused tables), r[] of the depth-2 states follows them
     int grid_blocks = 0;
+    bool packed = true;                   // record format: 4-byte words + tile index (final states fit 20 bits), else 8-byte records
+    // level-2 filter (ScanArgs::l2f_mode)
+    unsigned char *d_bm2 = nullptr;       // 2-byte-prefix bitmap, 256 rows of 32 bytes
+    int l2f_mode = 0, n_child = 0, bm2_rows = 0, sh_bm2 = 0;
+    unsigned child0 = 0, child1 = 0;
+    // tuning / test knobs, read from the environment ONCE, when a table is installed
+    unsigned lb_trigger = 300, spin_max = SPIN_MAX, fault = 0, ticket_ways_knob = 0;
+    std::string trace_file;
     std::string err;
     std::mutex mu;
 };
@@ -1314,6 +1545,24 @@ int ensure_status(pfac_ctx *ctx, Slot &s, uint64_t n_words) {
     s.flip = 0;
     s.status_cap = cap;
     return PFAC_OK;
+}
+
+int ensure_tiles(pfac_ctx *ctx, Slot &s, uint64_t n_entries) {
+    if (s.d_tile_first && s.tile_cap >= n_entries) return PFAC_OK;
+    if (s.d_tile_first) {
+        HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+        HIP_TRY(ctx, hipFree(s.d_tile_first));
+        s.d_tile_first = nullptr;
+    }
+    const uint64_t cap = n_entries < 4096 ? 4096 : n_entries + n_entries / 4;
+    HIP_TRY(ctx, hipMalloc((void **)&s.d_tile_first, cap * 8));
+    s.tile_cap = cap;
+    return PFAC_OK;
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
 }
 
 int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
@@ -1368,6 +1617,43 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     }
     ctx->shared_bytes = SH_D1 + ctx->d1_rows * 1024 + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 4, 16));
     if (fused && ctx->d1_rows == 0) ctx->shared_bytes += 1024;   // r[] of the depth-1 states by root byte
+    // ---- level-2 filter: the 2-byte-prefix bitmap is built on the device from the uploaded tables; a single-edge
+    // root with at most two grandchildren gets the bit-parallel form (their bytes), everything else the lookup form
+    if (!ctx->d_bm2) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bm2, 256 * 32));
+    hipLaunchKernelGGL(pfac_build_bm2_kernel, dim3(256), dim3(256), 0, 0, ctx->d_s0, ctx->d_r, ctx->d_T, ctx->width_bit,
+                       ctx->ht_size, reinterpret_cast<unsigned long long *>(ctx->d_bm2));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->l2f_mode = 2;
+    ctx->bm2_rows = 256;
+    ctx->n_child = 0;
+    ctx->child0 = ctx->child1 = 0;
+    if (fan == 1) {
+        unsigned char row[32];
+        HIP_TRY(ctx, hipMemcpy(row, ctx->d_bm2 + (size_t)rb * 32, 32, hipMemcpyDeviceToHost));
+        int nch = 0, ch[2] = {0, 0};
+        for (int c = 0; c < 256; c++)
+            if (row[c >> 3] >> (c & 7) & 1) { if (nch < 2) ch[nch] = c; nch++; }
+        ctx->bm2_rows = 1;
+        if (nch <= 2) {
+            ctx->l2f_mode = 1;
+            ctx->n_child = nch;
+            ctx->child0 = (unsigned)ch[0] * 0x01010101u;
+            ctx->child1 = (unsigned)ch[nch > 1 ? 1 : 0] * 0x01010101u;
+        }
+    }
+    const int l2f_env = env_int("PFAC_L2F", -1);          // 0: filter off; 2: lookup form even where the SWAR form applies
+    if (l2f_env == 0) ctx->l2f_mode = 0;
+    else if (l2f_env == 2) ctx->l2f_mode = 2;
+    ctx->sh_bm2 = ctx->shared_bytes;
+    if (ctx->l2f_mode == 2) ctx->shared_bytes += ctx->bm2_rows * 32;
+    // knobs (tuning and tests), read once per table install
+    ctx->lb_trigger = (unsigned)env_int("PFAC_LBD", 300);
+    ctx->spin_max = (unsigned)env_int("PFAC_SPIN_MAX", (int)SPIN_MAX);
+    if (ctx->spin_max < 64) ctx->spin_max = 64;
+    ctx->fault = (unsigned)env_int("PFAC_FAULT", 0);
+    ctx->ticket_ways_knob = (unsigned)env_int("PFAC_TICKET_WAYS", 0);
+    ctx->trace_file = getenv("PFAC_TRACE") ? getenv("PFAC_TRACE") : "";
     ctx->pw_bytes = (int)align_up((size_t)PW_FIXED + ctx->halo, 16);
     int nwb = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes + 1;     // compute waves + the coordinator (no LDS region)
     if (nwb > MAX_WAVES_PER_BLOCK) nwb = MAX_WAVES_PER_BLOCK;
@@ -1382,7 +1668,8 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->root_mode = fan == 1 ? 1 : 0;
     ctx->root_byte = (unsigned)rb * 0x01010101u;
     ctx->root_state = s0_host[rb];
-    ctx->stage_cap = ctx->num_final <= (1 << PACK_STATE_BITS) ? (unsigned)CAPW : 0u;
+    ctx->packed = ctx->num_final <= (1 << PACK_STATE_BITS) && !getenv("PFAC_WIDE");   // PFAC_WIDE: test knob, 8-byte records
+    ctx->stage_cap = ctx->packed ? (unsigned)CAPW : 0u;
     // dense-mode layout
     ctx->pw_bytes_d = (int)align_up((size_t)PW_FIXED_DENSE + ctx->halo, 16);
     int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
@@ -1514,6 +1801,9 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
         if (s.d_input) (void)hipFree(s.d_input);
         if (s.d_records) (void)hipFree(s.d_records);
         if (s.d_ctl) (void)hipFree(s.d_ctl);
+        if (s.d_tile_first) (void)hipFree(s.d_tile_first);
+        if (s.d_wide) (void)hipFree(s.d_wide);
+        if (s.d_dbg) (void)hipFree(s.d_dbg);
         if (s.d_sum) (void)hipFree(s.d_sum);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.ev0) (void)hipEventDestroy(s.ev0);
@@ -1523,6 +1813,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_d1) (void)hipFree(ctx->d_d1);
     if (ctx->d_T4) (void)hipFree(ctx->d_T4);
+    if (ctx->d_bm2) (void)hipFree(ctx->d_bm2);
     delete ctx;
 }
 
@@ -1578,7 +1869,7 @@ int pfac_slot_reserve(pfac_ctx *ctx, int slot, uint64_t input_bytes, uint64_t re
 }
 
 void *pfac_slot_input(pfac_ctx *ctx, int slot) { return check_slot(ctx, slot) ? nullptr : ctx->slots[slot].d_input; }
-pfac_record *pfac_slot_records(pfac_ctx *ctx, int slot) { return check_slot(ctx, slot) ? nullptr : ctx->slots[slot].d_records; }
+void *pfac_slot_records(pfac_ctx *ctx, int slot) { return check_slot(ctx, slot) ? nullptr : ctx->slots[slot].d_records; }
 void *pfac_slot_stream(pfac_ctx *ctx, int slot) { return check_slot(ctx, slot) ? nullptr : (void *)ctx->slots[slot].stream; }
 
 int pfac_slot_set_stream(pfac_ctx *ctx, int slot, void *stream_handle) {
@@ -1602,7 +1893,7 @@ int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, u
 }
 
 int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_owned, uint64_t n_avail,
-                    pfac_record *d_records, uint64_t capacity) {
+                    void *d_records, uint64_t capacity) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     if (!ctx->have_table) return fail(ctx, PFAC_E_STATE, "pfac_scan_async before a table upload");
@@ -1636,6 +1927,11 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     const uint64_t need = (n_batches + 6ull * ctx->grid_blocks + 8) * (uint64_t)ST_STRIDE;   // u64 words
     rc = ensure_status(ctx, s, need);
     if (rc) return rc;
+    rc = ensure_tiles(ctx, s, n_tiles + 1);
+    if (rc) return rc;
+    s.last_packed = ctx->packed;
+    s.last_records = d_records;
+    if (n_tiles == 0) HIP_TRY(ctx, hipMemsetAsync(s.d_tile_first, 0, 8, s.stream));   // total = 0
     unsigned *const cur = s.d_ctlbuf[s.flip], *const nxt = s.d_ctlbuf[1 - s.flip];
     if (n_tiles > 0 && s.clean[s.flip] < need)
         HIP_TRY(ctx, hipMemsetAsync(cur, 0, CTL_WORDS * 4 + align_up(need * 8, 16), s.stream));
@@ -1644,6 +1940,11 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         ScanArgs a;
         a.in = in; a.n_owned = n_owned; a.n_avail = n_avail;
         a.out = d_records; a.out_cap = capacity;
+        a.tile_first = s.d_tile_first;
+        a.packed = ctx->packed ? 1u : 0u;
+        a.l2f_mode = ctx->l2f_mode; a.child0 = ctx->child0; a.child1 = ctx->child1; a.n_child = ctx->n_child;
+        a.bm2 = ctx->d_bm2; a.bm2_rows = ctx->bm2_rows; a.sh_bm2 = ctx->sh_bm2;
+        a.spin_max = ctx->spin_max; a.fault = ctx->fault;
         a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T; a.T4 = ctx->d_T4;
         a.r_words = ctx->max_row; a.t_entries = ctx->ht_size;
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
@@ -1657,7 +1958,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;
         a.root_state = ctx->root_state;
-        a.lb_trigger = getenv("PFAC_LBD") ? (unsigned)atoi(getenv("PFAC_LBD")) : 300u;
+        a.lb_trigger = ctx->lb_trigger;
         a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
         a.nbuf = dense ? 1u : (unsigned)NBUF;
         a.sparse_cap = ctx->stage_cap;
@@ -1668,16 +1969,17 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.res = s.d_res;
         a.status = reinterpret_cast<unsigned long long *>(cur + CTL_WORDS);
         a.dbg = nullptr;
-        if (getenv("PFAC_TRACE")) {
+#ifdef PFAC_TRACE_BUILD
+        if (!ctx->trace_file.empty()) {
             if (!s.d_dbg) HIP_TRY(ctx, hipMalloc((void **)&s.d_dbg, 8 * 64 * 32 * 8));
             HIP_TRY(ctx, hipMemsetAsync(s.d_dbg, 0, 8 * 64 * 32 * 8, s.stream));
             a.dbg = s.d_dbg;
         }
+#endif
         const uint64_t want = n_batches;
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
         a.ticket_ways = grid < TICKET_WAYS ? (unsigned)grid : TICKET_WAYS;
-        if (getenv("PFAC_TICKET_WAYS") && atoi(getenv("PFAC_TICKET_WAYS")) >= 1 && (unsigned)atoi(getenv("PFAC_TICKET_WAYS")) < a.ticket_ways)
-            a.ticket_ways = (unsigned)atoi(getenv("PFAC_TICKET_WAYS"));
+        if (ctx->ticket_ways_knob >= 1 && ctx->ticket_ways_knob < a.ticket_ways) a.ticket_ways = ctx->ticket_ways_knob;
         void *kargs[] = {&a};
         HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
         s.clean[s.flip] = 0;                   // used by this scan
@@ -1699,16 +2001,20 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     HIP_TRY(ctx, hipEventSynchronize(s.ev1));
     s.pending = false;
     const uint64_t total = ((uint64_t)s.h_ctl[1] << 32) | s.h_ctl[0];
+    s.last_total = total;
     if (n_matches) *n_matches = total;
-    if (s.d_dbg && getenv("PFAC_TRACE")) {
+#ifdef PFAC_TRACE_BUILD
+    if (s.d_dbg && !ctx->trace_file.empty()) {
         std::vector<unsigned long long> h(8 * 64 * 32);
         if (hipMemcpy(h.data(), s.d_dbg, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *f = fopen(getenv("PFAC_TRACE"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            if (FILE *f = fopen(ctx->trace_file.c_str(), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         }
     }
+#endif
     if (s.h_ctl[2] != 0) {
         s.clean[0] = s.clean[1] = 0;           // whatever state the control buffers are in: zero them before the next scan
-        return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a look-back timeout");
+        return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a timeout (flags " + std::to_string(s.h_ctl[2]) +
+                                          ": 1 look-back, 4 arrivals, 8 record base, 16 batch ring)");
     }
     // Staging mode for the NEXT scans of this context: when more than a quarter of the tiles held more matches
     // than the small (three-buffer) staging area takes, go dense (one big buffer, emitted at once, no second
@@ -1733,15 +2039,79 @@ int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms) {
     return PFAC_OK;
 }
 
-int pfac_records_d2h(pfac_ctx *ctx, int slot, const pfac_record *d_records, pfac_record *host, uint64_t first, uint64_t n) {
+// Packed records [first, first+n) of the slot's last scan -> pfac_record at d_out (device), on the slot's stream.
+static int expand_records(pfac_ctx *ctx, Slot &s, const void *src, uint64_t first, uint64_t n, pfac_record *d_out) {
+    if (n == 0) return PFAC_OK;
+    if (!s.last_packed) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_out, static_cast<const pfac_record *>(src) + first, n * sizeof(pfac_record),
+                                    hipMemcpyDeviceToDevice, s.stream));
+        return PFAC_OK;
+    }
+    const uint64_t want = (s.last_tiles + 3) / 4;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    hipLaunchKernelGGL(pfac_expand_kernel, dim3(grid), dim3(256), 0, s.stream, static_cast<const unsigned *>(src),
+                       s.d_tile_first, (unsigned long long)s.last_tiles, (unsigned long long)first, (unsigned long long)n, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return PFAC_OK;
+}
+
+int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
-    const pfac_record *src = d_records ? d_records : s.d_records;
+    if (!s.scanned) return fail(ctx, PFAC_E_STATE, "no scan yet");
+    if (packed) *packed = s.last_packed ? 1 : 0;
+    if (n_tiles) *n_tiles = s.last_tiles;
+    return PFAC_OK;
+}
+
+int pfac_records_expand(pfac_ctx *ctx, int slot, const void *d_records, uint64_t first, uint64_t n, pfac_record *d_out) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    Slot &s = ctx->slots[slot];
+    const void *src = d_records ? d_records : s.d_records;
+    if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_expand without a scan");
+    if (!src || (!d_out && n) || ((uintptr_t)d_out & 7)) return fail(ctx, PFAC_E_ARG, "pfac_records_expand: bad buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return expand_records(ctx, s, src, first, n, d_out);
+}
+
+int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record *host, uint64_t first, uint64_t n) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    Slot &s = ctx->slots[slot];
+    const void *src = d_records ? d_records : s.d_records;
     if (!src || (!host && n)) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h: null buffer");
     if (n == 0) return PFAC_OK;
+    if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(host, src + first, n * sizeof(pfac_record), hipMemcpyDeviceToHost, s.stream));
+    if (!s.last_packed) {
+        HIP_TRY(ctx, hipMemcpyAsync(host, static_cast<const pfac_record *>(src) + first, n * sizeof(pfac_record),
+                                    hipMemcpyDeviceToHost, s.stream));
+        return PFAC_OK;
+    }
+    if (n > s.wide_cap) {
+        if (s.d_wide) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_wide)); s.d_wide = nullptr; s.wide_cap = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&s.d_wide, n * sizeof(pfac_record)));
+        s.wide_cap = n;
+    }
+    rc = expand_records(ctx, s, src, first, n, s.d_wide);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(host, s.d_wide, n * sizeof(pfac_record), hipMemcpyDeviceToHost, s.stream));
+    return PFAC_OK;
+}
+
+int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n,
+                            uint64_t *host_tile_first) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    Slot &s = ctx->slots[slot];
+    const void *src = d_records ? d_records : s.d_records;
+    if (!s.scanned || !s.last_packed) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h_packed: the slot's last scan did not produce packed records");
+    if (!src || (!host_words && n) || !host_tile_first) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(host_words, src, n * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(host_tile_first, s.d_tile_first, (s.last_tiles + 1) * 8, hipMemcpyDeviceToHost, s.stream));
     return PFAC_OK;
 }
 
@@ -1753,19 +2123,25 @@ int pfac_slot_sync(pfac_ctx *ctx, int slot) {
     return PFAC_OK;
 }
 
-int pfac_records_checksum(pfac_ctx *ctx, int slot, const pfac_record *d_records, uint64_t n, uint64_t base, uint64_t *checksum) {
+int pfac_records_checksum(pfac_ctx *ctx, int slot, const void *d_records, uint64_t n, uint64_t base, uint64_t *checksum) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     if (!checksum) return fail(ctx, PFAC_E_ARG, "null argument");
     if (!ctx->have_table) return fail(ctx, PFAC_E_STATE, "no table uploaded");
     Slot &s = ctx->slots[slot];
-    const pfac_record *src = d_records ? d_records : s.d_records;
+    const void *src = d_records ? d_records : s.d_records;
     if (!src && n) return fail(ctx, PFAC_E_ARG, "null record buffer");
+    if (n && !s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_checksum without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(s.d_sum, 0, 16, s.stream));
-    if (n) {
-        hipLaunchKernelGGL(pfac_checksum_kernel, dim3(1024), dim3(256), 0, s.stream, src, (unsigned long long)n,
-                           (unsigned long long)base, ctx->d_idmap, s.d_sum);
+    if (n && s.last_packed) {
+        hipLaunchKernelGGL(pfac_checksum_packed_kernel, dim3(1024), dim3(256), 0, s.stream, static_cast<const unsigned *>(src),
+                           s.d_tile_first, (unsigned long long)s.last_tiles, (unsigned long long)n, (unsigned long long)base,
+                           ctx->d_idmap, s.d_sum);
+        HIP_TRY(ctx, hipGetLastError());
+    } else if (n) {
+        hipLaunchKernelGGL(pfac_checksum_kernel, dim3(1024), dim3(256), 0, s.stream, static_cast<const pfac_record *>(src),
+                           (unsigned long long)n, (unsigned long long)base, ctx->d_idmap, s.d_sum);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemcpyAsync(s.h_ctl + 4, s.d_sum, 8, hipMemcpyDeviceToHost, s.stream));

@@ -566,31 +566,78 @@ static inline char *put_uint(char *p, uint64_t v, int min_width) {
     return p;
 }
 
-int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap) {
-    if (!file || (!rec && n)) return PFAC_E_ARG;
-    FILE *f = (FILE *)file;
+/* Where the records come from: wide pfac_record, or the compact device form (32-bit words + per-tile first index). */
+typedef struct {
+    const pfac_record *rec;
+    const uint32_t *words;
+    const uint64_t *tile_first;
+    uint64_t n_tiles;
+} rec_src;
+
+/* tile of packed record k: the t with tile_first[t] <= k < tile_first[t+1] (empty tiles skipped) */
+static uint64_t tile_of(const rec_src *s, uint64_t k) {
+    uint64_t lo = 0, hi = s->n_tiles;               /* invariant: tile_first[lo] <= k < tile_first[hi] */
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (s->tile_first[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+/* Lines of records [k0, k1) into p (pass 2) or only their byte count (p == NULL, pass 1). */
+static char *format_records(const rec_src *s, uint64_t k0, uint64_t k1, uint64_t base, const int32_t *idmap, char *p,
+                            uint64_t *bytes_out) {
+    uint64_t bytes = 0, t = 0;
+    if (s->words && k0 < k1) t = tile_of(s, k0);
+    for (uint64_t k = k0; k < k1; k++) {
+        uint64_t pos;
+        uint32_t st;
+        if (s->words) {
+            while (k >= s->tile_first[t + 1]) t++;
+            pos = base + t * PFAC_TILE_BYTES + PFAC_PACKED_POS(s->words[k]);
+            st = PFAC_PACKED_STATE(s->words[k]);
+        } else {
+            pos = base + s->rec[k].pos;
+            st = s->rec[k].state;
+        }
+        const int32_t id = idmap ? idmap[st] : (int32_t)st;
+        if (!p) {
+            int dp = 1, di = id < 0 ? 2 : 1;
+            for (uint64_t v = pos; v >= 10; v /= 10) dp++;
+            for (uint64_t v = id < 0 ? (uint64_t)(-(int64_t)id) : (uint64_t)id; v >= 10; v /= 10) di++;
+            bytes += 12 + (uint64_t)(dp < 4 ? 4 : dp) + 16 + (uint64_t)di + 1;
+            continue;
+        }
+        memcpy(p, "At position ", 12); p += 12;
+        p = put_uint(p, pos, 4);                                  /* %4d */
+        memcpy(p, ", match pattern ", 16); p += 16;
+        if (id < 0) { *p++ = '-'; p = put_uint(p, (uint64_t)(-(int64_t)id), 1); }
+        else p = put_uint(p, (uint64_t)id, 1);                    /* %d */
+        *p++ = '\n';
+    }
+    if (bytes_out) *bytes_out = bytes;
+    return p;
+}
+
+static int64_t emit_serial(FILE *f, const rec_src *s, uint64_t n, uint64_t base, const int32_t *idmap) {
     enum { CHUNK = 1 << 16, LINE_MAX_BYTES = 64 };
     char *buf = (char *)malloc((size_t)CHUNK * LINE_MAX_BYTES);
     if (!buf) return PFAC_E_NOMEM;
     int64_t total = 0;
     for (uint64_t k0 = 0; k0 < n; k0 += CHUNK) {
-        uint64_t k1 = k0 + CHUNK < n ? k0 + CHUNK : n;
-        char *p = buf;
-        for (uint64_t k = k0; k < k1; k++) {
-            memcpy(p, "At position ", 12); p += 12;
-            p = put_uint(p, base + rec[k].pos, 4);                /* %4d */
-            memcpy(p, ", match pattern ", 16); p += 16;
-            int32_t id = idmap ? idmap[rec[k].state] : (int32_t)rec[k].state;
-            if (id < 0) { *p++ = '-'; p = put_uint(p, (uint64_t)(-(int64_t)id), 1); }
-            else p = put_uint(p, (uint64_t)id, 1);                /* %d */
-            *p++ = '\n';
-        }
-        size_t len = (size_t)(p - buf);
+        const uint64_t k1 = k0 + CHUNK < n ? k0 + CHUNK : n;
+        const size_t len = (size_t)(format_records(s, k0, k1, base, idmap, buf, NULL) - buf);
         if (fwrite(buf, 1, len, f) != len) { free(buf); return PFAC_E_IO; }
         total += (int64_t)len;
     }
     free(buf);
     return total;
+}
+
+int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap) {
+    if (!file || (!rec && n)) return PFAC_E_ARG;
+    const rec_src s = {rec, NULL, NULL, 0};
+    return emit_serial((FILE *)file, &s, n, base, idmap);
 }
 
 /* ---- pattern-partition mode: merge of the per-partition match lists, the reference's
@@ -646,14 +693,8 @@ int64_t pfac_merge_partitions(const pfac_record *const *lists, const uint64_t *c
  * blocks and pwrite()s them in place from all threads.  Byte-identical to the serial emitter. ---- */
 enum { EMIT_BLOCK = 1 << 17, EMIT_LINE_MAX = 64 };
 
-static inline int ndigits(uint64_t v) {
-    int n = 1;
-    while (v >= 10) { v /= 10; n++; }
-    return n;
-}
-
 typedef struct {
-    const pfac_record *rec;
+    const rec_src *src;
     uint64_t n, base;
     const int32_t *idmap;
     uint64_t n_blocks;
@@ -675,26 +716,10 @@ static void *emit_worker(void *arg) {
     for (uint64_t b = (uint64_t)j->tid; b < j->n_blocks; b += (uint64_t)j->n_threads) {
         const uint64_t k0 = b * EMIT_BLOCK, k1 = k0 + EMIT_BLOCK < j->n ? k0 + EMIT_BLOCK : j->n;
         if (j->pass == 1) {
-            uint64_t bytes = 0;
-            for (uint64_t k = k0; k < k1; k++) {
-                const int dp = ndigits(j->base + j->rec[k].pos);
-                const int32_t id = j->idmap ? j->idmap[j->rec[k].state] : (int32_t)j->rec[k].state;
-                const int di = id < 0 ? 1 + ndigits((uint64_t)(-(int64_t)id)) : ndigits((uint64_t)id);
-                bytes += 12 + (uint64_t)(dp < 4 ? 4 : dp) + 16 + (uint64_t)di + 1;
-            }
-            j->block_bytes[b] = bytes;
+            format_records(j->src, k0, k1, j->base, j->idmap, NULL, &j->block_bytes[b]);
         } else {
-            char *p = buf;
-            for (uint64_t k = k0; k < k1; k++) {
-                memcpy(p, "At position ", 12); p += 12;
-                p = put_uint(p, j->base + j->rec[k].pos, 4);
-                memcpy(p, ", match pattern ", 16); p += 16;
-                const int32_t id = j->idmap ? j->idmap[j->rec[k].state] : (int32_t)j->rec[k].state;
-                if (id < 0) { *p++ = '-'; p = put_uint(p, (uint64_t)(-(int64_t)id), 1); }
-                else p = put_uint(p, (uint64_t)id, 1);
-                *p++ = '\n';
-            }
-            size_t len = (size_t)(p - buf), done = 0;
+            const size_t len = (size_t)(format_records(j->src, k0, k1, j->base, j->idmap, buf, NULL) - buf);
+            size_t done = 0;
             const int64_t off = j->file_base + (int64_t)j->block_bytes[b];
             while (done < len) {
                 ssize_t w = pwrite(j->fd, buf + done, len - done, off + (int64_t)done);
@@ -707,32 +732,31 @@ static void *emit_worker(void *arg) {
     return NULL;
 }
 
-int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
-                             int n_threads) {
-    if (!file || (!rec && n)) return PFAC_E_ARG;
-    if (n_threads < 2 || n < 4 * (uint64_t)EMIT_BLOCK) return pfac_emit_records(file, rec, n, base, idmap);
+static int64_t emit_mt(FILE *f, const rec_src *src, uint64_t n, uint64_t base, const int32_t *idmap, int n_threads) {
+    if (n_threads < 2 || n < 4 * (uint64_t)EMIT_BLOCK) return emit_serial(f, src, n, base, idmap);
     if (n_threads > 64) n_threads = 64;
-    FILE *f = (FILE *)file;
     if (fflush(f)) return PFAC_E_IO;
     const int fd = fileno(f);
     const long at = ftell(f);
     /* pipes are not seekable, and Linux pwrite() ignores the offset on O_APPEND descriptors: serial path */
-    if (fd < 0 || at < 0 || (fcntl(fd, F_GETFL) & O_APPEND)) return pfac_emit_records(file, rec, n, base, idmap);
+    if (fd < 0 || at < 0 || (fcntl(fd, F_GETFL) & O_APPEND)) return emit_serial(f, src, n, base, idmap);
     const uint64_t n_blocks = (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
     uint64_t *bb = (uint64_t *)malloc((size_t)n_blocks * sizeof(uint64_t));
     emit_job *jobs = (emit_job *)calloc((size_t)n_threads, sizeof(emit_job));
     pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
-    if (!bb || !jobs || !th) { free(bb); free(jobs); free(th); return PFAC_E_NOMEM; }
+    int *started = (int *)calloc((size_t)n_threads, sizeof(int));
+    if (!bb || !jobs || !th || !started) { free(bb); free(jobs); free(th); free(started); return PFAC_E_NOMEM; }
     int64_t total = 0;
     int rc = 0;
     for (int pass = 1; pass <= 2 && !rc; pass++) {
         for (int t = 0; t < n_threads; t++) {
-            emit_job j = {rec, n, base, idmap, n_blocks, bb, fd, (int64_t)at, pass, t, n_threads, 0};
+            emit_job j = {src, n, base, idmap, n_blocks, bb, fd, (int64_t)at, pass, t, n_threads, 0};
             jobs[t] = j;
-            if (pthread_create(&th[t], NULL, emit_worker, &jobs[t])) { jobs[t].rc = PFAC_E_NOMEM; emit_worker(&jobs[t]); th[t] = 0; }
+            started[t] = pthread_create(&th[t], NULL, emit_worker, &jobs[t]) == 0;
+            if (!started[t]) emit_worker(&jobs[t]);            /* no thread to be had: this share runs inline */
         }
         for (int t = 0; t < n_threads; t++) {
-            if (th[t]) pthread_join(th[t], NULL);
+            if (started[t]) pthread_join(th[t], NULL);
             if (jobs[t].rc) rc = jobs[t].rc;
         }
         if (pass == 1) {                            /* exclusive prefix: block sizes -> offsets */
@@ -741,8 +765,24 @@ int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uin
             total = (int64_t)acc;
         }
     }
-    free(bb); free(jobs); free(th);
+    free(bb); free(jobs); free(th); free(started);
     if (rc) return rc;
     if (fseek(f, at + (long)total, SEEK_SET)) return PFAC_E_IO;
     return total;
+}
+
+int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
+                             int n_threads) {
+    if (!file || (!rec && n)) return PFAC_E_ARG;
+    const rec_src s = {rec, NULL, NULL, 0};
+    return emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
+}
+
+int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_first, uint64_t n_tiles, uint64_t base,
+                         const int32_t *idmap, int n_threads) {
+    if (!file || !tile_first) return PFAC_E_ARG;
+    const uint64_t n = tile_first[n_tiles];
+    if (!words && n) return PFAC_E_ARG;
+    const rec_src s = {NULL, words, tile_first, n_tiles};
+    return emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
 }

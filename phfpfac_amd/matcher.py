@@ -45,6 +45,7 @@ class GpuMatcher:
         self.device = device
         self.n_streams = n_streams
         self.table: Optional[PfacTable] = None
+        self._keep = {}
         rc = self._L.pfac_ctx_create(int(device), int(n_streams), C.byref(self._ctx))
         if rc:
             self._ctx = C.c_void_p()
@@ -114,11 +115,12 @@ class GpuMatcher:
 
     def h2d(self, host: np.ndarray, slot: int = 0, dst_offset: int = 0) -> None:
         host = np.ascontiguousarray(host, dtype=np.uint8)
-        self._keep = host  # the copy is asynchronous
+        self._keep.setdefault(slot, []).append(host)   # the copy is asynchronous: released by sync()/scan_finish()
         self._check(self._L.pfac_slot_h2d(self._ctx, slot, host.ctypes.data, host.size, int(dst_offset)))
 
     def sync(self, slot: int = 0) -> None:
         self._check(self._L.pfac_slot_sync(self._ctx, slot))
+        self._keep.pop(slot, None)
 
     # -- the scan ---------------------------------------------------------
     def scan_async(self, n_owned: int, n_avail: Optional[int] = None, d_input=None, d_records=None,
@@ -144,6 +146,26 @@ class GpuMatcher:
             self._check(self._L.pfac_records_d2h(self._ctx, slot, _ptr(d_records), out.ctypes.data, int(first), int(n)))
             self.sync(slot)
         return out
+
+    def scan_format(self, slot: int = 0) -> Tuple[bool, int]:
+        """(packed, n_tiles) of the slot's last scan: packed = 4-byte words + tile index on the device."""
+        pk, nt = C.c_int(0), C.c_uint64(0)
+        self._check(self._L.pfac_scan_format(self._ctx, slot, C.byref(pk), C.byref(nt)))
+        return bool(pk.value), nt.value
+
+    def expand_records(self, n: int, d_out, slot: int = 0, d_records=None, first: int = 0) -> None:
+        """Records [first, first+n) of the slot's last scan as 8-byte ``pfac_record`` into the DEVICE buffer ``d_out``
+        (asynchronous on the slot's stream) -- what the RCCL record gather sends."""
+        self._check(self._L.pfac_records_expand(self._ctx, slot, _ptr(d_records), int(first), int(n), _ptr(d_out)))
+
+    def packed_to_host(self, n: int, slot: int = 0, d_records=None) -> Tuple[np.ndarray, np.ndarray]:
+        """The compact device form itself: (uint32 words [n], uint64 tile_first [n_tiles + 1])."""
+        _, nt = self.scan_format(slot)
+        words = np.empty(int(n), dtype=np.uint32)
+        tf = np.empty(nt + 1, dtype=np.uint64)
+        self._check(self._L.pfac_records_d2h_packed(self._ctx, slot, _ptr(d_records), words.ctypes.data, int(n), tf.ctypes.data))
+        self.sync(slot)
+        return words, tf
 
     def checksum(self, n: int, base: int = 0, slot: int = 0, d_records=None) -> int:
         s = C.c_uint64(0)

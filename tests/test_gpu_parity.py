@@ -521,15 +521,19 @@ def test_rccl_path_single_rank(resolve):
         lo, hi, end = pdist.shard_read_range(n_total, 0, 1, table2.halo)
         buf = torch.zeros(end - lo + 64, dtype=torch.uint8, device=dev)
         buf[: end - lo] = torch.from_numpy(data[lo:end].copy()).to(dev)
-        rec_t = torch.empty(1 << 17, dtype=torch.int64, device=dev)       # 8-byte records, torch-owned
+        rec_t = torch.empty(1 << 17, dtype=torch.int64, device=dev)       # torch-owned record buffer (either form fits)
+        wide_t = torch.empty(1 << 17, dtype=torch.int64, device=dev)      # 8-byte records for the gather
         with GpuMatcher(0, 1) as g:
             g.load_table_device(blob, blob.numel(), 0, host_table=table2)
             g.scan_async(hi - lo, end - lo, d_input=buf, d_records=rec_t, capacity=rec_t.numel())
             n, over = g.scan_finish(0)
             assert not over
+            assert g.scan_format(0) == (True, -(-(hi - lo) // TILE))      # compact words + tile index on the device
+            g.expand_records(n, wide_t, d_records=rec_t)                  # -> pfac_record, still on the device
+            g.sync(0)
         counts = pdist.gather_counts(n, dev)
         assert counts == [n]
-        gathered = pdist.gather_records(rec_t, n, counts, dst=0)
+        gathered = pdist.gather_records(wide_t, n, counts, dst=0)
         got = pdist.split_gathered(gathered, counts, n_total, 1)
     finally:
         dist.destroy_process_group()
