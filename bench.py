@@ -132,7 +132,8 @@ def main():
     ap.add_argument("--workload", default="text1g_experimentpattern", choices=sorted(WORKLOADS))
     ap.add_argument("--bytes-per-gpu", type=int, default=GIB)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also time the other workloads (short) and report them")
+    ap.add_argument("--extra", action="store_true", help="(default now) also time the other workloads (short) and report them")
+    ap.add_argument("--no-extra", action="store_true", help="time the headline workload only")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also report the CPU baseline on this many host threads")
     args = ap.parse_args()
 
@@ -314,7 +315,7 @@ def main():
                      "kernel_ms_min": round(res["kernel_ms_min"], 4),
                      "algorithmic_bytes_per_launch": res["n_owned"]},
     }
-    if args.extra:
+    if not args.no_extra:
         out["other_workloads"] = {}
         for name in sorted(WORKLOADS):
             if name == args.workload:

@@ -97,9 +97,10 @@ constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
 constexpr int CAPW_DENSE = 2048;
 constexpr int PW_FIXED_DENSE = WTILE + QCAP * 2 + CAPW_DENSE * 4;
 
-// One look-back word per 64 bytes: eight owners no longer write the cache line their successors are polling
-// (sparse workloads +2.5 %); the price is 64 B instead of 8 B of control memory per batch.
-constexpr long long ST_STRIDE = 8;         // u64 words between consecutive look-back words
+#ifndef PFAC_ST_STRIDE
+#define PFAC_ST_STRIDE 8
+#endif
+constexpr long long ST_STRIDE = PFAC_ST_STRIDE;   // u64 words between consecutive batch status words
 constexpr unsigned long long ST_AGG = 1ull << 62;
 constexpr unsigned long long ST_INCL = 2ull << 62;
 constexpr unsigned long long ST_VAL = (1ull << 62) - 1;
@@ -165,7 +166,8 @@ struct ScanArgs {
     unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy, written with
                                    // plain stores only: [0..1] total matches (u64) by the workgroup that resolves the last
                                    // batch, [2] error flags and [3] tiles denser than sparse_cap by the last workgroup to leave
-    unsigned long long *status;    // one look-back word per batch
+    unsigned long long *status;    // one aggregate word per batch ...
+    unsigned long long *gentot;    // ... and one total per generation of GEN batches (behind them, same zeroed buffer)
     unsigned long long *dbg;       // PFAC_TRACE_BUILD only: per-round timestamps (10 ns units), else null
 };
 
@@ -222,6 +224,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 //
 // LDS header (unsigned words), rings of 8 rounds indexed by r & 7:
 constexpr int RING = 8;
+#ifndef PFAC_AHEAD
+#define PFAC_AHEAD 2
+#endif
+constexpr int AHEAD = PFAC_AHEAD;          // rounds the batch ring runs ahead of the coordinator's own round
+static_assert(AHEAD >= 2 && AHEAD <= RING - 3, "ring depth");
+#ifndef PFAC_LOAD_DEPTH
+#define PFAC_LOAD_DEPTH 1
+#endif
+constexpr int LOAD_DEPTH = PFAC_LOAD_DEPTH; // tiles a compute wave keeps in flight ahead of the one it scans (1 or 2)
+static_assert(LOAD_DEPTH == 1 || (LOAD_DEPTH == 2 && AHEAD >= 3), "two tiles in flight need the ring three rounds ahead");
 constexpr int H_BATCH = 0;                 // batch id of round r
 constexpr int H_EPOCH = 8;                 // == r + 1 once H_BATCH (and a zeroed H_ARRIVED) are valid
 constexpr int H_ARRIVED = 16;              // compute waves that have posted their count
@@ -261,112 +273,84 @@ __device__ __forceinline__ bool lds_wait_eq(const unsigned *p, unsigned want, co
 }
 
 // ---------------------------------------------------------------------------
-// decoupled look-back over per-tile match counts.  Each status word is ONE
-// naturally aligned 8-byte granule {flag:2, value:62} moved only by relaxed
-// agent-scope atomics (global_load/store ... sc1): the data is the flag, so no
-// fence is needed and nothing else is handed between workgroups.
+// Record placement across workgroups: a batch's first record index = the matches of all batches before it.
+// Each status word is ONE naturally aligned 8-byte granule {flag:2, value:62} moved only by relaxed agent-scope
+// atomics (global_load/store ... sc1): the data is the flag, so no fence is needed and nothing else is handed
+// between workgroups.
+//
+// The classic decoupled look-back (every batch publishes its aggregate, then its inclusive prefix; a batch sums
+// aggregates backwards until it meets an inclusive prefix) is a SERIAL chain here: the 256 workgroups draw the 256
+// batches of a "generation" at about the same time, so the predecessors inside a 64-wide window never hold an
+// inclusive prefix yet, and the inclusive frontier advances by one window per memory round trip -- 64 batches x
+// 60 KiB per ~1 us = 3.9 TB/s, which is where every sparse workload sat.  So the chain is cut to ONE hop per
+// GENERATION of 256 batches:
+//   status[g]   = aggregate of batch g, published once, never rewritten;
+//   gentot[s]   = matches of generations 0..s, published by whoever holds the LAST batch of generation s;
+//   base(g)     = gentot[s-1] + sum of status[g'] over the batches g' < g of g's own generation s
+// -- up to 255 words, four wave-wide loads issued together, ONE round trip, no dependence on any other batch's
+// look-back.  The words a batch needs were published two rounds before it reads them (the coordinator resolves a
+// round two iterations after publishing it), so in steady state nothing is polled twice; gentot[s-1] was
+// published a whole round earlier still.
 __device__ __forceinline__ unsigned long long st_load(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_store(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+constexpr unsigned GEN = 256;              // batches per generation
+constexpr int GEN_W = GEN / WAVE;          // wave-wide loads that cover one
+constexpr long long GT_STRIDE = 8;         // u64 words between consecutive generation totals (one per 64 bytes)
 
-// A tile first publishes its own count (aggregate); tile 0's count is already its inclusive prefix.
-__device__ __forceinline__ void publish_aggregate(unsigned long long *status, unsigned tile, unsigned long long tot, int lane) {
-    if (lane == 0) st_store(&status[(long long)tile * ST_STRIDE], (tile == 0 ? ST_INCL : ST_AGG) | tot);
+__device__ __forceinline__ void publish_aggregate(unsigned long long *status, unsigned g, unsigned long long tot, int lane) {
+    if (lane == 0) st_store(&status[(long long)g * ST_STRIDE], ST_AGG | tot);
 }
 
-// All 64 lanes of one wave.  Returns the number of matches in all batches before `tile`
-// (wave-uniform) and publishes the batch's inclusive prefix.  A few hundred batches are in flight
-// chip-wide (one per workgroup), most of them of the same "generation", so the window is WIDE:
-// 4 x 64 predecessors are fetched at once (one memory round trip), and the scan stops at the nearest
-// predecessor that already knows its inclusive prefix -- only predecessors nearer than that one have
-// to be published before this batch can finish.  Every spin is bounded: on timeout the error word is
-// set and the kernel still terminates.  An aggregate is published without waiting for anything, so a predecessor
-// polled here belongs to a workgroup that is running or done -- or has not been drawn yet by its residue class
-// (see TICKET_WAYS), in which case the poll lasts until a workgroup of that class draws it.
-// Window widths (in waves = 64 predecessors each): the window the coordinator loads ahead of time (PRE) and the
-// windows the loop loads when that one did not reach an inclusive prefix (LOOP).  Narrow is better than wide: all
-// workgroups read the same few cache lines of look-back words while their owners write them, and the wider the
-// windows the longer those hot lines queue (4 x 64 -> 1 x 64: +11..15 % on the sparse workloads).
-#ifndef PFAC_LB_PRE
-#define PFAC_LB_PRE 1
-#endif
-#ifndef PFAC_LB_LOOP
-#define PFAC_LB_LOOP 1
-#endif
-constexpr int LB_PRE = PFAC_LB_PRE, LB_LOOP = PFAC_LB_LOOP, LB_MAX = LB_PRE > LB_LOOP ? LB_PRE : LB_LOOP;
-#ifndef PFAC_LB_LANES
-#define PFAC_LB_LANES 64
-#endif
-constexpr int LB_LANES = PFAC_LB_LANES;    // lanes of the last wave of a window that take part (fewer: a shorter window still)
-static_assert(LB_LANES == 64 || (LB_PRE == 1 && LB_LOOP == 1), "partial waves only with one-wave windows");
 struct LbWindow {
-    unsigned long long st[LB_PRE];
+    unsigned long long st[GEN_W];          // lane L, chunk c: aggregate of batch  gen_start + 64 c + L  (if that is < g)
+    unsigned long long gt;                 // lane 0: total of the previous generations
 };
-// Issue the loads of the window right behind `tile` (no wait): the coordinator does this ahead of the round in
-// which it needs the answer, so the memory round trip overlaps the arrivals.
-__device__ __forceinline__ void lookback_issue(unsigned long long *status, unsigned tile, int lane, LbWindow &w) {
+// Issue the loads batch g's base needs (no wait): the coordinator does this ahead of the round in which it needs
+// the answer, so the memory round trip overlaps the arrivals.  Words that are not needed read as "published, 0".
+__device__ __forceinline__ void lookback_issue(unsigned long long *status, unsigned long long *gentot, unsigned g, int lane, LbWindow &w) {
+    const unsigned s = g / GEN, k = g % GEN;
 #pragma unroll
-    for (int k = 0; k < LB_PRE; k++) {
-        const long long idx = (long long)tile - 1 - lane - WAVE * k;
-        w.st[k] = 0;
-        if (lane < LB_LANES) w.st[k] = idx >= 0 ? st_load(&status[idx * ST_STRIDE]) : ST_INCL;   // before batch 0: inclusive prefix 0
+    for (int c = 0; c < GEN_W; c++) {
+        const unsigned pos = (unsigned)c * WAVE + (unsigned)lane;
+        w.st[c] = ST_AGG;
+        if (pos < k) w.st[c] = st_load(&status[(long long)(s * GEN + pos) * ST_STRIDE]);
     }
+    w.gt = ST_AGG;
+    if (s > 0 && lane == 0) w.gt = st_load(&gentot[(long long)(s - 1) * GT_STRIDE]);
 }
-// pre != nullptr: the first window was loaded earlier by lookback_issue().
-__device__ unsigned long long lookback(unsigned long long *status, unsigned tile, unsigned long long tot, int lane,
-                                       const ErrCh &err, const LbWindow *pre = nullptr, bool publish = true) {
-    if (tile == 0) return 0;
-    unsigned long long excl = 0;
-    long long top = (long long)tile - 1;              // nearest predecessor not yet accounted for
+// All 64 lanes of one wave.  Returns the number of matches in all batches before g (wave-uniform); the holder of a
+// generation's last batch publishes the generation total.  pre != nullptr: the words were loaded earlier by
+// lookback_issue().  The spin is bounded: on timeout the error word is set and the kernel still terminates.
+__device__ unsigned long long lookback(unsigned long long *status, unsigned long long *gentot, unsigned g, unsigned long long tot,
+                                       int lane, const ErrCh &err, const LbWindow *pre = nullptr, bool publish = true) {
+    LbWindow w;
+    if (pre) w = *pre;
+    else lookback_issue(status, gentot, g, lane, w);
     unsigned spins = 0;
     bool failed = false;
-    bool use_pre = pre != nullptr;
-    while (top >= 0) {
-        const int nw = use_pre ? LB_PRE : LB_LOOP;    // width of this window (wave-uniform)
-        unsigned long long st[LB_MAX];
+    for (;;) {
+        bool ok = (w.gt >> 62) != 0;
 #pragma unroll
-        for (int k = 0; k < LB_MAX; k++) {
-            const long long idx = top - lane - WAVE * k;   // position WAVE*k + lane behind `top`
-            st[k] = 0;
-            if (k < nw) {
-                if (use_pre) st[k] = pre->st[k < LB_PRE ? k : 0];
-                else if (lane < LB_LANES) st[k] = idx >= 0 ? st_load(&status[idx * ST_STRIDE]) : ST_INCL;   // before batch 0: inclusive prefix 0
-            }
-        }
-        use_pre = false;
-        // first unpublished and first inclusive position in the window (wave-uniform)
-        const unsigned long long part = LB_LANES == 64 ? ~0ull : ((1ull << (LB_LANES & 63)) - 1ull);
-        int pz = (nw - 1) * WAVE + LB_LANES, pi = pz;
-#pragma unroll
-        for (int k = LB_MAX - 1; k >= 0; k--) {
-            if (k >= nw) continue;
-            const unsigned long long z = __ballot((st[k] >> 62) == 0) & part;
-            const unsigned long long in = __ballot((st[k] >> 62) == 2) & part;
-            if (z) pz = WAVE * k + __ffsll((long long)z) - 1;
-            if (in) pi = WAVE * k + __ffsll((long long)in) - 1;
-        }
-        const int upto = pi < pz ? pi : pz - 1;       // positions 0..upto are usable now (all published)
-        if (pi >= pz && pz == 0) {                    // the nearest one is not published yet: poll again
-            if (++spins >= err.spin_max) { failed = true; break; }
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        unsigned long long v = 0;
-#pragma unroll
-        for (int k = 0; k < LB_MAX; k++)
-            if (k < nw && WAVE * k + lane <= upto) v += st[k] & ST_VAL;
-        excl += wave_sum62(v);
-        if (pi < pz) break;                           // reached a predecessor with an inclusive prefix
-        top -= upto + 1;                              // consumed the published aggregates; continue behind them
+        for (int c = 0; c < GEN_W; c++) ok = ok && (w.st[c] >> 62) != 0;
+        if (__ballot(!ok) == 0) break;
+        if (++spins >= err.spin_max) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+        lookback_issue(status, gentot, g, lane, w);
     }
+    unsigned long long v = w.gt & ST_VAL;
+#pragma unroll
+    for (int c = 0; c < GEN_W; c++) v += w.st[c] & ST_VAL;
+    unsigned long long excl = wave_sum62(v);
     if (failed) {
         if (lane == 0) err_set(err, 1u);
         excl = 0;
     }
-    if (lane == 0 && publish) st_store(&status[(long long)tile * ST_STRIDE], ST_INCL | ((excl + tot) & ST_VAL));
+    if (publish && g % GEN == GEN - 1 && lane == 0)
+        st_store(&gentot[(long long)(g / GEN) * GT_STRIDE], ST_INCL | ((excl + tot) & ST_VAL));
     return excl;
 }
 
@@ -928,16 +912,24 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     }
     __syncthreads();                           // the only workgroup barrier
 
+#ifdef PFAC_ABL_NOCOORD                        // ablation builds only: static tiles, no coordinator, counts dropped
+    if (wave == nc) return;
+#endif
     if (wave == nc) {
         // ================= coordinator =================
         __builtin_amdgcn_s_setprio(3);         // tiny, latency-critical instruction stream
         // batch tickets: the atomic is ISSUED one iteration before its result is needed, so its ~1.3 us
         // round trip never blocks the coordinator
+#ifdef PFAC_ABL_STATIC                         // ablation builds only (tools/abn.sh): batches dealt round-robin, no atomic
+        unsigned abl_seq = 0;
+        auto ticket = [&]() -> unsigned { return (abl_seq++) * gridDim.x + blockIdx.x; };
+#else
         auto ticket = [&]() -> unsigned {
             unsigned g = 0;
             if (lane == 0) g = atomicAdd(&a.ctl[(blockIdx.x % a.ticket_ways) * 64u], 1u) * a.ticket_ways + blockIdx.x % a.ticket_ways;
             return g;                          // valid in lane 0 (not waited for here)
         };
+#endif
         auto publish_batch = [&](unsigned r, unsigned g_lane0) -> unsigned {   // ring entry of round r; returns batch id
             if (lane == 0) {
                 lds_store(&hdr[H_ARRIVED + (r & 7)], 0u);
@@ -948,16 +940,16 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             }
             return __builtin_amdgcn_readfirstlane(g_lane0);
         };
-        unsigned g_cur = publish_batch(0, ticket());
-        unsigned g_nxt = publish_batch(1, ticket());
-        unsigned t_pending = ticket();         // for round 2, published at the top of iteration 0
-        // The look-back of round r normally runs one round LATE (after round r+1's aggregate went out):
-        // by then every batch of the same generation has published its aggregate, so it costs one
-        // memory round trip instead of a wait for the slowest workgroup; the compute waves emit two
-        // rounds late and never notice.
+        unsigned g[AHEAD];                     // batch ids of rounds r .. r+AHEAD-1 (published)
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) g[k] = publish_batch((unsigned)k, ticket());
+        unsigned t_pending = ticket();         // for round AHEAD, published at the top of iteration 0
+        // The base of round r is computed one round LATE (after round r+1's aggregate went out): by then every
+        // batch of the same generation has published its aggregate, so it costs one memory round trip instead
+        // of a wait for the slowest workgroup; the compute waves emit two rounds late and never notice.
         // Rounds in flight in the coordinator: round r (waiting for its counts), round r-1 (aggregate
-        // published, look-back window loads just issued) and round r-2 (window loads issued one round
-        // ago -> finished from registers now).
+        // published, its status loads just issued) and round r-2 (loads issued one round ago -> finished from
+        // registers now).
         struct Pend { bool on; unsigned r, g; unsigned long long tot, first, end; unsigned cnt; bool mute; };
         Pend p1 = {false, 0, 0, 0, 0, 0, 0, false}, p2 = {false, 0, 0, 0, 0, 0, 0, false};
         LbWindow win = {};
@@ -965,7 +957,12 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         // resolve a round: batch base from the look-back, then every compute wave's first record index -- to LDS for
         // the waves and, as the tiles' first-record indices, to the tile index of the record array
         auto resolve = [&](const Pend &p, const LbWindow *pre) {
-            const unsigned long long excl = lookback(a.status, p.g, p.tot, lane, err, pre, !p.mute);
+#ifdef PFAC_ABL_NOLB                           // ablation builds only: no record placement across workgroups (wrong bases)
+            const unsigned long long excl = 0;
+            (void)pre;
+#else
+            const unsigned long long excl = lookback(a.status, a.gentot, p.g, p.tot, lane, err, pre, !p.mute);
+#endif
             // exclusive prefix of the waves' counts (lane c holds wave c's count)
             const unsigned incl = wave_incl_scan(p.cnt);
             const unsigned long long wb = excl + (incl - p.cnt);
@@ -983,10 +980,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             }
         };
         for (unsigned r = 0;; r++) {
+            const unsigned g_cur = g[0];
             const unsigned long long first = (unsigned long long)g_cur * (unsigned)nc;
             if (first >= a.n_tiles) break;     // batches are handed out in order: nothing left for this workgroup
-            const unsigned g_nxt2 = publish_batch(r + 2, t_pending);   // two rounds ahead of the compute waves
-            t_pending = ticket();                           // for round r+3
+            const unsigned g_new = publish_batch(r + AHEAD, t_pending);   // AHEAD rounds ahead of this iteration
+            t_pending = ticket();                           // for round r+AHEAD+1
 #ifdef PFAC_TRACE_BUILD
             const bool trace = a.dbg && blockIdx.x < 8 && r < 64 && lane == 0;
             unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + (r & 63)) * 32;
@@ -997,13 +995,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             // (b) round r: wait for the counts, publish the aggregate
             const unsigned long long left = a.n_tiles - first;
             const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
-            // While waiting: once round r-1's aggregate has been out for lb_trigger ticks (3.0 us: time for the
-            // workgroups ahead of this one to have resolved THEIR round r-1, so the window ends at an inclusive prefix),
-            // start loading its look-back window -- the memory round trip then overlaps the rest of the arrivals
-            // instead of sitting in front of the next iteration.  Short rounds (sparse input) never get there and load
-            // the window after this round's aggregate went out, as before; loading it earlier than that costs them 12 %
-            // (the window then usually ends in aggregates only and a second, blocking one is needed), loading it
-            // this early gains the match-dense headline 7 %.
+            // While waiting: once round r-1's aggregate has been out for lb_trigger ticks (time for the other
+            // workgroups to have published THEIR batch of that generation), start loading the status words its base
+            // needs -- the memory round trip then overlaps the rest of the arrivals instead of sitting in front of the
+            // next iteration.  Short rounds never get there and load them after this round's aggregate went out.
             bool win_issued = !p1.on;
             {
                 bool failed = false;
@@ -1015,7 +1010,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                         __builtin_amdgcn_s_sleep(1);
                         arr = lds_load(&hdr[H_ARRIVED + (r & 7)]);
                     }
-                    if (!failed && arr != n_valid) { lookback_issue(a.status, p1.g, lane, win); win_issued = true; }
+                    if (!failed && arr != n_valid) { lookback_issue(a.status, a.gentot, p1.g, lane, win); win_issued = true; }
                 }
                 if (failed || !lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
             }
@@ -1027,7 +1022,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             t_pub = __builtin_amdgcn_s_memrealtime();
             const Pend cur = {true, r, g_cur, tot, first, first + n_valid, c, mute};
             // (c) round r-1 moves on: issue its look-back window now, finish it next iteration
-            if (p1.on) { if (!win_issued) lookback_issue(a.status, p1.g, lane, win); p2 = p1; p1.on = false; }
+            if (p1.on) { if (!win_issued) lookback_issue(a.status, a.gentot, p1.g, lane, win); p2 = p1; p1.on = false; }
             p1 = cur;
             if (lds_load(&hdr[H_URGENT + (r & 7)]) != 0) {  // a wave overflowed its staging: it is waiting for this base
                 if (p2.on) { resolve(p2, &win); p2.on = false; }
@@ -1037,8 +1032,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #ifdef PFAC_TRACE_BUILD
             if (trace) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = g_cur; }
 #endif
-            g_cur = g_nxt;
-            g_nxt = g_nxt2;
+#pragma unroll
+            for (int k = 0; k + 1 < AHEAD; k++) g[k] = g[k + 1];
+            g[AHEAD - 1] = g_new;
         }
         if (p2.on) resolve(p2, &win);
         if (p1.on) resolve(p1, nullptr);
@@ -1057,10 +1053,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     unsigned *stage0 = reinterpret_cast<unsigned *>(tile + WTILE + a.halo + QCAP * 2);
     const bool root_final = ROOT == 1 && (unsigned)a.root_state < (unsigned)a.num_final;
 
-    // prefetch registers: the wave's 4 KiB + halo
-    u32x4 w[SUBS];
-    u32x4 hw = {0u, 0u, 0u, 0u};
-    auto issue_loads = [&](unsigned long long tt) {
+    // prefetch registers: the wave's 4 KiB + halo, LOAD_DEPTH tiles ahead of the one being scanned (set A / set B)
+    u32x4 wA[SUBS], wB[SUBS];
+    u32x4 hA = {0u, 0u, 0u, 0u}, hB = {0u, 0u, 0u, 0u};
+    auto issue_loads = [&](unsigned long long tt, u32x4 (&w)[SUBS], u32x4 &hw) {
         const unsigned long long tb = tt * WTILE;
         const unsigned long long remain = a.n_avail - tb;
         const unsigned lm = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
@@ -1070,6 +1066,18 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #pragma unroll
         for (int j = 0; j < SUBS; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, j * SUB + lane * 16, 0, 0);
         if (lane * 16 < a.halo) hw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, WTILE + lane * 16, 0, 0);
+    };
+    // this wave's tile of round rr; false: there is none (the input is used up) or the ring timed out.
+    // Tile numbers are wave-uniform: as scalars they make the buffer descriptor of the tile loads a scalar too
+    // (a descriptor in VGPRs costs a readfirstlane "waterfall" loop around every load)
+    auto probe = [&](unsigned rr, unsigned long long &tt) -> bool {
+#ifdef PFAC_ABL_NOCOORD
+        tt = ((unsigned long long)rr * gridDim.x + blockIdx.x) * (unsigned)nc + (unsigned)wave;
+        return tt < a.n_tiles;
+#endif
+        if (!lds_wait_eq(&hdr[H_EPOCH + (rr & 7)], rr + 1, err, 16u)) return false;
+        tt = (unsigned long long)__builtin_amdgcn_readfirstlane(hdr[H_BATCH + (rr & 7)]) * (unsigned)nc + (unsigned)wave;
+        return tt < a.n_tiles;
     };
     // first record index of this wave's tile of round rr (computed by the coordinator)
     auto record_base = [&](unsigned rr, unsigned long long &base) -> bool {
@@ -1082,18 +1090,22 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     };
 
     unsigned r = 0;
-    if (!lds_wait_eq(&hdr[H_EPOCH], 1u, err, 16u)) return;
-    // tile numbers are wave-uniform: as scalars they make the buffer descriptor of the tile loads a scalar too
-    // (a descriptor in VGPRs costs a readfirstlane "waterfall" loop around every load)
-    unsigned long long t = (unsigned long long)__builtin_amdgcn_readfirstlane(hdr[H_BATCH]) * (unsigned)nc + (unsigned)wave;
-    if (t >= a.n_tiles) return;
-    issue_loads(t);
+    unsigned long long t = 0, t_n1 = 0;        // tiles of rounds r and (LOAD_DEPTH == 2) r+1
+    bool have_n1 = false;
+    if (!probe(0, t)) return;
+    issue_loads(t, wA, hA);
+    if (LOAD_DEPTH == 2) {
+        have_n1 = probe(1, t_n1);
+        if (have_n1) issue_loads(t_n1, wB, hB);
+    }
 
     // pending[k]: the tile scanned k+1 rounds ago still sits in its staging buffer
     bool have1 = false, have2 = false;
     unsigned cnt1 = 0, cnt2 = 0, buf = 0;      // buf: staging buffer of the current round, (r % NBUF)
 
-    for (;;) {
+    // One round: w / hw hold this round's tile; they are refilled with the tile LOAD_DEPTH rounds ahead as soon as
+    // their bytes sit in LDS.  Returns false after the wave's last tile.
+    auto round_body = [&](u32x4 (&w)[SUBS], u32x4 &hw) -> bool {
         const unsigned long long tile_base = t * WTILE;
         const unsigned long long remain = a.n_avail - tile_base;           // > 0
         const unsigned lim = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
@@ -1103,7 +1115,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + (r & 63)) * 32;
 #endif
         PFAC_STAMP(trace, 4);
-        // ---- registers -> LDS (tile + halo), then start the next round's loads right away
+        // ---- registers -> LDS (tile + halo), then start the loads of the tile LOAD_DEPTH rounds ahead right away
 #pragma unroll
         for (int j = 0; j < SUBS; j++) *reinterpret_cast<u32x4 *>(tile + j * SUB + lane * 16) = w[j];
         if (lane * 16 < a.halo) *reinterpret_cast<u32x4 *>(tile + WTILE + lane * 16) = hw;
@@ -1113,13 +1125,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         }
         wave_lds_sync();
         PFAC_STAMP(trace, 5);
-        bool more = lds_wait_eq(&hdr[H_EPOCH + ((r + 1) & 7)], r + 2, err, 16u);
-        unsigned long long t_next = 0;
-        if (more) {
-            t_next = (unsigned long long)__builtin_amdgcn_readfirstlane(hdr[H_BATCH + ((r + 1) & 7)]) * (unsigned)nc + (unsigned)wave;
-            more = t_next < a.n_tiles;
-        }
-        if (more) issue_loads(t_next);
+        unsigned long long t_far = 0;
+        const bool more_far = (LOAD_DEPTH == 1 || have_n1) && probe(r + LOAD_DEPTH, t_far);
+        if (more_far) issue_loads(t_far, w, hw);
 
         // ---- root test -> 32-bit survivor mask per lane per half-tile; level-2 filter -> which of them are kept
         // (yield a record or need a walk) and which of those are deep (need the walk)
@@ -1187,6 +1195,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         const bool overflow = cnt > a.stage_cap;
         const bool now = overflow || a.nbuf == 1;          // this tile is emitted right away (needs its base at once)
         unsigned arrival = 0;
+#ifdef PFAC_ABL_NOCOORD
+        if (false)
+#endif
         if (lane == 0) {
             hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
             if (now) lds_store(&hdr[H_URGENT + (r & 7)], 1u);
@@ -1223,9 +1234,21 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         have2 = have1; cnt2 = cnt1;
         have1 = !now; cnt1 = (unsigned)cnt;
         buf = a.nbuf == 1 ? 0u : (buf + 1) % NBUF;
-        if (!more) break;
-        t = t_next;
+        if (LOAD_DEPTH == 1) {
+            if (!more_far) return false;
+            t = t_far;
+        } else {
+            if (!have_n1) return false;
+            t = t_n1;
+            t_n1 = t_far;
+            have_n1 = more_far;
+        }
         r++;
+        return true;
+    };
+    for (;;) {
+        if (!round_body(wA, hA)) break;
+        if (LOAD_DEPTH == 2 && !round_body(wB, hB)) break;
     }
     // drain: the last two rounds' tiles (staged in buffers buf+1 [two rounds ago] and buf+2 [last round])
     if (have2 && cnt2 != 0) {
@@ -1924,7 +1947,8 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     // slot has two control buffers: every scan zeroes, in its own prologue, what the next scan needs in the other
     // one, so back-to-back scans of similar size need no memset; anything else falls back to one.
     const uint64_t n_batches = (n_tiles + wpb - 2) / (wpb - 1);
-    const uint64_t need = (n_batches + 6ull * ctx->grid_blocks + 8) * (uint64_t)ST_STRIDE;   // u64 words
+    const uint64_t n_status = n_batches + 6ull * ctx->grid_blocks + 8;       // + the tickets every workgroup draws past the end
+    const uint64_t need = n_status * (uint64_t)ST_STRIDE + (n_status / GEN + 2) * (uint64_t)GT_STRIDE;   // u64 words
     rc = ensure_status(ctx, s, need);
     if (rc) return rc;
     rc = ensure_tiles(ctx, s, n_tiles + 1);
@@ -1968,6 +1992,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.zero_vec = (unsigned)((CTL_WORDS * 4 + align_up(need * 8, 16)) / 16);
         a.res = s.d_res;
         a.status = reinterpret_cast<unsigned long long *>(cur + CTL_WORDS);
+        a.gentot = a.status + n_status * (uint64_t)ST_STRIDE;
         a.dbg = nullptr;
 #ifdef PFAC_TRACE_BUILD
         if (!ctx->trace_file.empty()) {

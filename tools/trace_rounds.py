@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "trace.bin")
 os.environ["PFAC_TRACE"] = out
+os.environ["PFAC_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ab", "libpfac_hip_trace.so")   # make -C phfpfac_amd/csrc trace
 import numpy as np, torch
 from phfpfac_amd import GpuMatcher, PfacTable
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
