@@ -127,15 +127,20 @@ typedef struct pfac_record {
     uint32_t state;     /* final state reached (== index into idmap) */
 } pfac_record;
 /*
- * On the DEVICE the scan writes the COMPACT form of the same ordered list (half the HBM and PCIe bytes): one 32-bit
- * word per match,  (pos & 4095) | state << 12,  plus tile_first[t] = index of the first record of 4 KiB input tile t
- * (tile_first[n_tiles] = total), so  pos = t * 4096 + (word & 4095)  for tile_first[t] <= i < tile_first[t+1].
- * Automata with more than 2^20 final states keep 8-byte pfac_record on the device as well
- * (pfac_scan_format tells which).  pfac_records_d2h / pfac_records_expand deliver pfac_record either way.
+ * On the DEVICE the scan writes the COMPACT form of the same list (half the HBM and PCIe bytes): one 32-bit word per
+ * match,  (pos & 4095) | state << 12,  into a record HEAP, plus an ordered TILE INDEX: the records of 4 KiB input
+ * tile t are the PFAC_TIX_COUNT(tile_index[t]) words that start at word PFAC_TIX_FIRST(tile_index[t]), in (position,
+ * pattern length) order, with  pos = t * 4096 + (word & 4095).  Walking the index in tile order yields the reference's
+ * output order; the heap itself has small gaps and no global order (a workgroup fills chunks of it with the tiles it
+ * scans -- a globally contiguous array would cost a chip-wide prefix over batches that are still being scanned).
+ * Automata with more than 2^20 final states keep 8-byte pfac_record in the heap (pfac_scan_format tells which).
+ * pfac_records_d2h / pfac_records_expand deliver ONE sorted pfac_record array either way.
  */
 #define PFAC_TILE_BYTES 4096
 #define PFAC_PACKED_POS(word) ((uint32_t)(word) & 4095u)
 #define PFAC_PACKED_STATE(word) ((uint32_t)(word) >> 12)
+#define PFAC_TIX_FIRST(e) ((uint64_t)(e) & ((1ull << 40) - 1))
+#define PFAC_TIX_COUNT(e) ((uint32_t)((uint64_t)(e) >> 40))
 /* idmap == NULL: rec.state already holds the pattern id (the output of pfac_merge_partitions). */
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap);
 /* Same bytes, produced by n_threads host threads (size pass, prefix sum, format + pwrite in place); the serial
@@ -143,10 +148,10 @@ int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64
  * serial emitter for small n, n_threads < 2 or pipes. */
 int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
                              int n_threads);
-/* The same text straight from the compact device form (words + tile index as pfac_records_d2h_packed delivers
- * them): position = base + t * 4096 + PFAC_PACKED_POS(word), pattern = idmap[PFAC_PACKED_STATE(word)].
- * n_threads < 2: serial. */
-int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_first, uint64_t n_tiles, uint64_t base,
+/* The same text straight from the compact device form (record heap + tile index as pfac_records_d2h_packed
+ * delivers them), tiles in order: position = base + t * 4096 + PFAC_PACKED_POS(word), pattern =
+ * idmap[PFAC_PACKED_STATE(word)].  n_threads < 2: serial. */
+int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_index, uint64_t n_tiles, uint64_t base,
                          const int32_t *idmap, int n_threads);
 /* Merge of per-partition match lists, replaces main.cc:304-324.  lists[k] (counts[k] records, sorted by
  * position as the scan emits them) comes from partition k of pfac_table_build_file_part(); the result is
@@ -203,38 +208,43 @@ int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, u
  *   n_avail   bytes readable from d_input, n_owned <= n_avail; walks that
  *             start in the owned range may read up to n_avail (the halo of
  *             max_pat_len-1 bytes that belongs to the next shard) and never beyond
- *   d_records device pointer for the ordered compact records, 16-B aligned, NULL = the slot's;
+ *   d_records device pointer for the record heap, 16-B aligned, NULL = the slot's;
  *             capacity x 4 bytes are written in the compact form, capacity x 8 in the wide one
- *   capacity  records that fit; the count is exact even when it overflows
- * Records come out sorted by (pos, pattern length) == the reference's output
- * order (main.cc:341-349); the tile index of the compact form lives in the slot.
- * Asynchronous on the slot's stream.
+ *   capacity  records the heap holds.  It needs some slack over the match count (chunks a workgroup has not
+ *             filled: at most capacity/16, plus gaps below 1 %); the match count is exact even when the
+ *             heap overflows, and pfac_scan_capacity_hint() then says what to reserve
+ * Through the tile index (which lives in the slot) the records are ordered by (pos, pattern length) == the
+ * reference's output order (main.cc:341-349).  Asynchronous on the slot's stream.
  */
 int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_owned, uint64_t n_avail,
                     void *d_records, uint64_t capacity);
 /* Wait for the slot and fetch the exact number of matches.  Returns
  * PFAC_E_OVERFLOW (with *n_matches set) when capacity was exceeded. */
 int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches);
+/* After pfac_scan_finish: a record capacity that the same scan fits (the finished scan's heap use + margin). */
+int pfac_scan_capacity_hint(pfac_ctx *ctx, int slot, uint64_t *capacity);
 /* Kernel time of the slot's last scan (hipEvent pair around the launch, the
  * analogue of "2. MASTER: The elapsed time is %f ms", master_kernel.cu:400-421). */
 int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms);
-/* D2H of records [first, first+n) (the compact replacement of the dense
+/* D2H of records [first, first+n) of the sorted sequence as pfac_record (the compact replacement of the dense
  * cudaMemcpy D2H, master_kernel.cu:428).  Asynchronous; pfac_slot_sync() completes it. */
 int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record *host, uint64_t first, uint64_t n);
 int pfac_slot_sync(pfac_ctx *ctx, int slot);
-/* Record form of the slot's last scan: *packed = 1 compact words + tile index, 0 pfac_record; *n_tiles = tiles scanned. */
-int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles);
-/* Records [first, first+n) of the slot's last scan as pfac_record in DEVICE memory (d_out, 8-B aligned), on the slot's
- * stream -- for consumers that stay on the GPU (the RCCL record gather). */
+/* Record form of the slot's last finished scan: *packed = 1 compact words, 0 pfac_record in the heap; *n_tiles =
+ * tiles scanned = entries of the tile index; *used = heap records in use (<= capacity unless it overflowed). */
+int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles, uint64_t *used);
+/* Records [first, first+n) of the slot's last scan, SORTED, as pfac_record in DEVICE memory (d_out, 8-B aligned), on
+ * the slot's stream -- for consumers that stay on the GPU (the RCCL record gather). */
 int pfac_records_expand(pfac_ctx *ctx, int slot, const void *d_records, uint64_t first, uint64_t n, pfac_record *d_out);
-/* D2H of the compact form itself: words [0, n) and the n_tiles + 1 entries of the tile index (4 bytes per match over
- * PCIe instead of 8; pfac_emit_packed() prints from it).  PFAC_E_STATE when the last scan was not compact. */
-int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n,
-                            uint64_t *host_tile_first);
+/* D2H of the compact form itself: heap words [0, n_words) (n_words = *used of pfac_scan_format) and the n_tiles
+ * entries of the tile index (4 bytes per match over PCIe instead of 8; pfac_emit_packed() prints from it).
+ * PFAC_E_STATE when the last scan was not compact. */
+int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n_words,
+                            uint64_t *host_tile_index);
 
-/* Order-independent 64-bit checksum of n records (sum over records of
- * mix(base+pos, idmap[state])), computed on the GPU; used for full-size
- * parity checks where materialising the text is not practical. */
+/* Order-independent 64-bit checksum of ALL records of the slot's last scan (sum over records of
+ * mix(base+pos, idmap[state])), computed on the GPU; used for full-size parity checks where materialising
+ * the text is not practical.  n = the scan's match count (0: checksum of nothing). */
 int pfac_records_checksum(pfac_ctx *ctx, int slot, const void *d_records, uint64_t n, uint64_t base,
                           uint64_t *checksum);
 

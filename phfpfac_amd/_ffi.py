@@ -76,7 +76,7 @@ HIP_SYMBOLS = (
     "pfac_slot_records", "pfac_slot_stream", "pfac_slot_set_stream", "pfac_slot_h2d", "pfac_scan_async",
     "pfac_scan_finish", "pfac_scan_elapsed_ms", "pfac_records_d2h", "pfac_slot_sync", "pfac_records_checksum",
     "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_trace_table_compat", "pfac_scan_format",
-    "pfac_records_expand", "pfac_records_d2h_packed",
+    "pfac_records_expand", "pfac_records_d2h_packed", "pfac_scan_capacity_hint",
 )
 
 _host = None
@@ -162,7 +162,8 @@ def hip_lib() -> C.CDLL:
         L.pfac_scan_finish.argtypes = [vp, i, C.POINTER(u64)]
         L.pfac_scan_elapsed_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
         L.pfac_records_d2h.argtypes = [vp, i, vp, vp, u64, u64]
-        L.pfac_scan_format.argtypes = [vp, i, C.POINTER(i), C.POINTER(u64)]
+        L.pfac_scan_format.argtypes = [vp, i, C.POINTER(i), C.POINTER(u64), C.POINTER(u64)]
+        L.pfac_scan_capacity_hint.argtypes = [vp, i, C.POINTER(u64)]
         L.pfac_records_expand.argtypes = [vp, i, vp, u64, u64, vp]
         L.pfac_records_d2h_packed.argtypes = [vp, i, vp, vp, u64, vp]
         L.pfac_slot_sync.argtypes = [vp, i]

@@ -134,9 +134,16 @@ static int read_parallel(int fd, void *dst, uint64_t n, uint64_t off, int n_thre
 static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap) {
     uint64_t n = 0;
     int rc = pfac_scan_finish(ctx, slot, &n);
-    if (rc == PFAC_E_OVERFLOW) {
-        *cap = n + n / 8 + 4096;
-        if ((rc = pfac_slot_reserve(ctx, slot, 0, *cap))) return fail(w, ctx, rc, "reserve");
+    /* a record heap that was too small is grown and the chunk (still in the slot's input buffer) scanned again; a
+     * protocol timeout (PFAC_E_INTERNAL: e.g. another kernel held the CUs this scan's workgroups needed) gets one retry */
+    for (int attempt = 0, retried = 0; (rc == PFAC_E_OVERFLOW && attempt < 4) || (rc == PFAC_E_INTERNAL && !retried); attempt++) {
+        if (rc == PFAC_E_INTERNAL) retried = 1;
+        else {
+            uint64_t hint = 0;
+            if ((rc = pfac_scan_capacity_hint(ctx, slot, &hint))) return fail(w, ctx, rc, "capacity hint");
+            *cap = hint > 2 * *cap ? hint : 2 * *cap;
+            if ((rc = pfac_slot_reserve(ctx, slot, 0, *cap))) return fail(w, ctx, rc, "reserve");
+        }
         if ((rc = pfac_scan_async(ctx, slot, NULL, c->n_owned, c->n_avail, NULL, 0))) return fail(w, ctx, rc, "scan");
         rc = pfac_scan_finish(ctx, slot, &n);
     }

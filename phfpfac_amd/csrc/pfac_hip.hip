@@ -90,20 +90,18 @@ constexpr int D1_N2_MAX = 2048;            // ... so at most this many depth-2 s
 // bytes) sits at ScanArgs::sh_bm2, behind them
 constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
-constexpr int NBUF = 3;                    // staging buffers: a tile's records are emitted two rounds later
+#ifndef PFAC_NBUF
+#define PFAC_NBUF 2
+#endif
+constexpr int NBUF = PFAC_NBUF;            // staging buffers: a tile's records are emitted NBUF-1 rounds later
+constexpr int LAG = NBUF - 1;
+static_assert(NBUF == 2 || NBUF == 3, "one or two rounds of emission lag");
 constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
 // Dense mode (most tiles hold more matches than CAPW, e.g. a dictionary on text): ONE big staging buffer per
 // wave and synchronous emission -- fewer waves fit, but a tile is walked once instead of twice.
 constexpr int CAPW_DENSE = 2048;
 constexpr int PW_FIXED_DENSE = WTILE + QCAP * 2 + CAPW_DENSE * 4;
 
-#ifndef PFAC_ST_STRIDE
-#define PFAC_ST_STRIDE 8
-#endif
-constexpr long long ST_STRIDE = PFAC_ST_STRIDE;   // u64 words between consecutive batch status words
-constexpr unsigned long long ST_AGG = 1ull << 62;
-constexpr unsigned long long ST_INCL = 2ull << 62;
-constexpr unsigned long long ST_VAL = (1ull << 62) - 1;
 // Batch tickets: one address sustains ~85 M atomics/s, and at 4 TB/s with 60 KiB per ticket the workgroups ask for
 // 65 M/s -- the single counter was the floor of the whole kernel (3.9 us per round with the scan compiled out).  So
 // there are TICKET_WAYS counters, 256 bytes apart: workgroup j draws from counter j % ways and holds batches
@@ -115,19 +113,21 @@ constexpr unsigned long long ST_VAL = (1ull << 62) - 1;
 #define PFAC_TICKET_WAYS 4
 #endif
 constexpr unsigned TICKET_WAYS = PFAC_TICKET_WAYS;
-constexpr unsigned CTL_WORDS = 64u * TICKET_WAYS;      // control header in 32-bit words: one 256-byte line per counter
+constexpr unsigned CTL_WORDS = 64u * (TICKET_WAYS + 1);   // control header in 32-bit words: one 256-byte line per ticket counter + the cursor's
 constexpr unsigned SPIN_MAX = 1u << 22;    // bounded spins (default; PFAC_SPIN_MAX): ~0.5 s of LDS polls, seconds of global polls
 // words of the control header (first ticket line) the kernel reports through: device memory, ordinary device atomics
-constexpr unsigned CTL_ERR = 32, CTL_OVF = 33, CTL_DONE = 34;
+constexpr unsigned CTL_ERR = 32, CTL_OVF = 33, CTL_DONE = 34, CTL_TOTAL = 36 /* u64: matches */;
+constexpr unsigned CTL_CURSOR = 64u * TICKET_WAYS;     // u64: first free record of the heap (on a line of its own)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ScanArgs {
     const unsigned char *in;
     unsigned long long n_owned, n_avail;
-    void *out;                            // packed: unsigned[out_cap] (pos:12 | state:20); else pfac_record[out_cap]
+    void *out;                            // the record heap; packed: unsigned[out_cap] (pos:12 | state:20); else pfac_record[out_cap]
     unsigned long long out_cap;
-    unsigned long long *tile_first;       // [n_tiles + 1]: index of each tile's first record; [n_tiles] = total
+    unsigned long long *tile_index;       // [n_tiles]: first record of the tile | its record count << 40
+    unsigned chunk;                       // records a workgroup takes from the heap cursor at a time (0: exact allocations only)
     unsigned packed;                      // record format of this scan (1: 4-byte words + tile_first, 0: 8-byte records)
     const int *s0;
     const int *r;
@@ -152,22 +152,19 @@ struct ScanArgs {
     const unsigned char *bm2;             // mode 2: bit (b0 << 8 | b1) set iff a path b0 b1 leaves the root
     int bm2_rows, sh_bm2;                 // rows staged in LDS (256, or 1 = the root byte's row) at this LDS offset
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
-    unsigned nbuf;                        // staging buffers per wave: 3 = emit two rounds late, 1 = emit at once (dense mode)
+    unsigned nbuf;                        // staging buffers per wave: NBUF = emit NBUF-1 rounds late, 1 = emit at once (dense mode)
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
     unsigned n_tiles;
-    unsigned lb_trigger;           // 10 ns ticks after a round's aggregate went out before its look-back window may be loaded (PFAC_LBD)
     unsigned spin_max;             // bound of every spin loop
-    unsigned fault;                // test knob (PFAC_FAULT): bit 0 = workgroup 1 never publishes its second batch
-    unsigned *ctl;                 // batch ticket counters (device memory), 64 words apart; [CTL_ERR/OVF/DONE]: error
-                                   // flags, tiles denser than sparse_cap, workgroups that have left
+    unsigned fault;                // test knob (PFAC_FAULT): bit 0 = workgroup 1 never publishes the record bases of its second round
+    unsigned *ctl;                 // control header (device memory): batch ticket counters 64 words apart; [CTL_ERR/OVF/DONE/TOTAL]:
+                                   // error flags, tiles denser than sparse_cap, workgroups that have left, matches; [CTL_CURSOR]
     unsigned ticket_ways;          // counters in use: min(TICKET_WAYS, grid)
-    uint4 *zero_next;              // the slot's OTHER control buffer: this launch zeroes it for the next one ...
+    uint4 *zero_next;              // the slot's OTHER control header: this launch zeroes it for the next one ...
     unsigned zero_vec;             // ... this many 16-byte units (no memset between back-to-back scans)
     unsigned *res;                 // host-mapped pinned words the host reads after the stream sync, no D2H copy, written with
-                                   // plain stores only: [0..1] total matches (u64) by the workgroup that resolves the last
-                                   // batch, [2] error flags and [3] tiles denser than sparse_cap by the last workgroup to leave
-    unsigned long long *status;    // one aggregate word per batch ...
-    unsigned long long *gentot;    // ... and one total per generation of GEN batches (behind them, same zeroed buffer)
+                                   // plain stores by the last workgroup to leave: [0..1] matches (u64), [2] error flags,
+                                   // [3] tiles denser than sparse_cap, [4..5] heap cursor = records of capacity used (u64)
     unsigned long long *dbg;       // PFAC_TRACE_BUILD only: per-round timestamps (10 ns units), else null
 };
 
@@ -237,8 +234,7 @@ static_assert(LOAD_DEPTH == 1 || (LOAD_DEPTH == 2 && AHEAD >= 3), "two tiles in 
 constexpr int H_BATCH = 0;                 // batch id of round r
 constexpr int H_EPOCH = 8;                 // == r + 1 once H_BATCH (and a zeroed H_ARRIVED) are valid
 constexpr int H_ARRIVED = 16;              // compute waves that have posted their count
-constexpr int H_READY = 24;                // == r + 1 once H_GBASE is valid
-constexpr int H_URGENT = 32;               // != 0: a wave of round r needs its base right away (staging overflow)
+constexpr int H_READY = 24;                // == r + 1 once H_WBASE of round r is valid
 constexpr int H_CNT = 48;                  // 16 words per round: match count of each compute wave
 constexpr int H_WBASE = H_CNT + RING * 16; // 32 words per round: {lo, hi} first record index of each compute wave
 constexpr int H_OVF = H_WBASE + RING * 32;  // tiles of this workgroup with more matches than sparse_cap
@@ -273,86 +269,24 @@ __device__ __forceinline__ bool lds_wait_eq(const unsigned *p, unsigned want, co
 }
 
 // ---------------------------------------------------------------------------
-// Record placement across workgroups: a batch's first record index = the matches of all batches before it.
-// Each status word is ONE naturally aligned 8-byte granule {flag:2, value:62} moved only by relaxed agent-scope
-// atomics (global_load/store ... sc1): the data is the flag, so no fence is needed and nothing else is handed
-// between workgroups.
+// Record placement.  The record array is a HEAP, the tile index is what is ordered: tile t's records are the
+// tile_index[t] >> 40 words (records) that start at tile_index[t] & (2^40 - 1), in (position, pattern length) order;
+// tiles are placed wherever their workgroup's current chunk of the array has room.  A workgroup owns a CHUNK of the
+// array at a time, taken from one global cursor with a single atomic (and one spare chunk is always on order, so
+// the atomic's round trip is never waited for); tiles fill the chunk back to back, a batch that does not fit in the
+// rest of the chunk continues in the next one from the first tile that does not fit, a batch larger than a chunk
+// gets an exact allocation of its own.
 //
-// The classic decoupled look-back (every batch publishes its aggregate, then its inclusive prefix; a batch sums
-// aggregates backwards until it meets an inclusive prefix) is a SERIAL chain here: the 256 workgroups draw the 256
-// batches of a "generation" at about the same time, so the predecessors inside a 64-wide window never hold an
-// inclusive prefix yet, and the inclusive frontier advances by one window per memory round trip -- 64 batches x
-// 60 KiB per ~1 us = 3.9 TB/s, which is where every sparse workload sat.  So the chain is cut to ONE hop per
-// GENERATION of 256 batches:
-//   status[g]   = aggregate of batch g, published once, never rewritten;
-//   gentot[s]   = matches of generations 0..s, published by whoever holds the LAST batch of generation s;
-//   base(g)     = gentot[s-1] + sum of status[g'] over the batches g' < g of g's own generation s
-// -- up to 255 words, four wave-wide loads issued together, ONE round trip, no dependence on any other batch's
-// look-back.  The words a batch needs were published two rounds before it reads them (the coordinator resolves a
-// round two iterations after publishing it), so in steady state nothing is polled twice; gentot[s-1] was
-// published a whole round earlier still.
-__device__ __forceinline__ unsigned long long st_load(unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_store(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-constexpr unsigned GEN = 256;              // batches per generation
-constexpr int GEN_W = GEN / WAVE;          // wave-wide loads that cover one
-constexpr long long GT_STRIDE = 8;         // u64 words between consecutive generation totals (one per 64 bytes)
-
-__device__ __forceinline__ void publish_aggregate(unsigned long long *status, unsigned g, unsigned long long tot, int lane) {
-    if (lane == 0) st_store(&status[(long long)g * ST_STRIDE], ST_AGG | tot);
-}
-
-struct LbWindow {
-    unsigned long long st[GEN_W];          // lane L, chunk c: aggregate of batch  gen_start + 64 c + L  (if that is < g)
-    unsigned long long gt;                 // lane 0: total of the previous generations
-};
-// Issue the loads batch g's base needs (no wait): the coordinator does this ahead of the round in which it needs
-// the answer, so the memory round trip overlaps the arrivals.  Words that are not needed read as "published, 0".
-__device__ __forceinline__ void lookback_issue(unsigned long long *status, unsigned long long *gentot, unsigned g, int lane, LbWindow &w) {
-    const unsigned s = g / GEN, k = g % GEN;
-#pragma unroll
-    for (int c = 0; c < GEN_W; c++) {
-        const unsigned pos = (unsigned)c * WAVE + (unsigned)lane;
-        w.st[c] = ST_AGG;
-        if (pos < k) w.st[c] = st_load(&status[(long long)(s * GEN + pos) * ST_STRIDE]);
-    }
-    w.gt = ST_AGG;
-    if (s > 0 && lane == 0) w.gt = st_load(&gentot[(long long)(s - 1) * GT_STRIDE]);
-}
-// All 64 lanes of one wave.  Returns the number of matches in all batches before g (wave-uniform); the holder of a
-// generation's last batch publishes the generation total.  pre != nullptr: the words were loaded earlier by
-// lookback_issue().  The spin is bounded: on timeout the error word is set and the kernel still terminates.
-__device__ unsigned long long lookback(unsigned long long *status, unsigned long long *gentot, unsigned g, unsigned long long tot,
-                                       int lane, const ErrCh &err, const LbWindow *pre = nullptr, bool publish = true) {
-    LbWindow w;
-    if (pre) w = *pre;
-    else lookback_issue(status, gentot, g, lane, w);
-    unsigned spins = 0;
-    bool failed = false;
-    for (;;) {
-        bool ok = (w.gt >> 62) != 0;
-#pragma unroll
-        for (int c = 0; c < GEN_W; c++) ok = ok && (w.st[c] >> 62) != 0;
-        if (__ballot(!ok) == 0) break;
-        if (++spins >= err.spin_max) { failed = true; break; }
-        __builtin_amdgcn_s_sleep(2);
-        lookback_issue(status, gentot, g, lane, w);
-    }
-    unsigned long long v = w.gt & ST_VAL;
-#pragma unroll
-    for (int c = 0; c < GEN_W; c++) v += w.st[c] & ST_VAL;
-    unsigned long long excl = wave_sum62(v);
-    if (failed) {
-        if (lane == 0) err_set(err, 1u);
-        excl = 0;
-    }
-    if (publish && g % GEN == GEN - 1 && lane == 0)
-        st_store(&gentot[(long long)(g / GEN) * GT_STRIDE], ST_INCL | ((excl + tot) & ST_VAL));
-    return excl;
-}
+// Why not one globally contiguous, sorted array: that needs every batch's first record index = the matches of ALL
+// earlier batches, i.e. a prefix over batches that are being scanned by other workgroups at the same time.  Both
+// forms of it were built and measured (decoupled look-back over 64-batch windows; per-generation totals with one
+// hop per 256 batches): with two rounds of staging as slack, every workgroup still ends up waiting for the slowest
+// one of its generation, round after round -- 12 % of the match-dense headline and 15-25 % of the sparse workloads
+// (ablation build PFAC_ABL_NOLB vs the full kernel).  Consumers lose nothing: they walk the tile index in order
+// (pfac_records_expand / pfac_records_d2h deliver one sorted pfac_record array, pfac_emit_packed prints from the
+// heap directly), the gaps are below 1 % of the array, and the chunk atomics are a few per microsecond.
+constexpr unsigned long long TIX_BASE_MASK = (1ull << 40) - 1;   // tile index word = first record | count << 40
+constexpr int TIX_CNT_SHIFT = 40;
 
 // ---------------------------------------------------------------------------
 // One step of the perfect-hash lookup (master_kernel.cu:52-63): returns the
@@ -933,7 +867,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         auto publish_batch = [&](unsigned r, unsigned g_lane0) -> unsigned {   // ring entry of round r; returns batch id
             if (lane == 0) {
                 lds_store(&hdr[H_ARRIVED + (r & 7)], 0u);
-                lds_store(&hdr[H_URGENT + (r & 7)], 0u);
                 lds_store(&hdr[H_BATCH + (r & 7)], g_lane0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 lds_store(&hdr[H_EPOCH + (r & 7)], r + 1);
@@ -944,45 +877,20 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) g[k] = publish_batch((unsigned)k, ticket());
         unsigned t_pending = ticket();         // for round AHEAD, published at the top of iteration 0
-        // The base of round r is computed one round LATE (after round r+1's aggregate went out): by then every
-        // batch of the same generation has published its aggregate, so it costs one memory round trip instead
-        // of a wait for the slowest workgroup; the compute waves emit two rounds late and never notice.
-        // Rounds in flight in the coordinator: round r (waiting for its counts), round r-1 (aggregate
-        // published, its status loads just issued) and round r-2 (loads issued one round ago -> finished from
-        // registers now).
-        struct Pend { bool on; unsigned r, g; unsigned long long tot, first, end; unsigned cnt; bool mute; };
-        Pend p1 = {false, 0, 0, 0, 0, 0, 0, false}, p2 = {false, 0, 0, 0, 0, 0, 0, false};
-        LbWindow win = {};
-        unsigned long long t_pub = 0;          // when this workgroup's last aggregate went out (100 MHz ticks)
-        // resolve a round: batch base from the look-back, then every compute wave's first record index -- to LDS for
-        // the waves and, as the tiles' first-record indices, to the tile index of the record array
-        auto resolve = [&](const Pend &p, const LbWindow *pre) {
-#ifdef PFAC_ABL_NOLB                           // ablation builds only: no record placement across workgroups (wrong bases)
-            const unsigned long long excl = 0;
-            (void)pre;
-#else
-            const unsigned long long excl = lookback(a.status, a.gentot, p.g, p.tot, lane, err, pre, !p.mute);
-#endif
-            // exclusive prefix of the waves' counts (lane c holds wave c's count)
-            const unsigned incl = wave_incl_scan(p.cnt);
-            const unsigned long long wb = excl + (incl - p.cnt);
-            if (lane < nc) {
-                hdr[H_WBASE + (p.r & 7) * 32 + lane * 2] = (unsigned)wb;
-                hdr[H_WBASE + (p.r & 7) * 32 + lane * 2 + 1] = (unsigned)(wb >> 32);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) lds_store(&hdr[H_READY + (p.r & 7)], p.r + 1);
-            if (p.first + (unsigned)lane < p.end) a.tile_first[p.first + (unsigned)lane] = wb;
-            if (lane == 0 && p.end >= a.n_tiles) {             // this batch holds the last tile: grand total
-                a.tile_first[a.n_tiles] = excl + p.tot;
-                a.res[0] = (unsigned)(excl + p.tot);
-                a.res[1] = (unsigned)((excl + p.tot) >> 32);
-            }
+        // the heap: this workgroup's current chunk [ch_base, ch_base + ch_size), ch_used records of it taken, and the
+        // chunk on order (the atomic was issued when the current one came into use; its value sits in lane 0)
+        unsigned long long *cursor = reinterpret_cast<unsigned long long *>(a.ctl + CTL_CURSOR);
+        auto order_chunk = [&]() -> unsigned long long {
+            unsigned long long v = 0;
+            if (lane == 0 && a.chunk) v = __hip_atomic_fetch_add(cursor, (unsigned long long)a.chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;                          // valid in lane 0 (not waited for here)
         };
+        unsigned long long ch_base = 0, spare = order_chunk(), local_total = 0;
+        unsigned ch_size = 0, ch_used = 0;
         for (unsigned r = 0;; r++) {
             const unsigned g_cur = g[0];
             const unsigned long long first = (unsigned long long)g_cur * (unsigned)nc;
-            if (first >= a.n_tiles) break;     // batches are handed out in order: nothing left for this workgroup
+            if (first >= a.n_tiles) break;     // batch ids only grow: nothing left for this workgroup
             const unsigned g_new = publish_batch(r + AHEAD, t_pending);   // AHEAD rounds ahead of this iteration
             t_pending = ticket();                           // for round r+AHEAD+1
 #ifdef PFAC_TRACE_BUILD
@@ -990,45 +898,50 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             unsigned long long *tr = a.dbg + ((size_t)blockIdx.x * 64 + (r & 63)) * 32;
 #endif
             PFAC_STAMP(trace, 0);
-            // (a) round r-2: its window loads were issued a whole round ago
-            if (p2.on) { resolve(p2, &win); p2.on = false; }
-            // (b) round r: wait for the counts, publish the aggregate
+            // ---- round r: wait for the counts of its tiles
             const unsigned long long left = a.n_tiles - first;
             const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
-            // While waiting: once round r-1's aggregate has been out for lb_trigger ticks (time for the other
-            // workgroups to have published THEIR batch of that generation), start loading the status words its base
-            // needs -- the memory round trip then overlaps the rest of the arrivals instead of sitting in front of the
-            // next iteration.  Short rounds never get there and load them after this round's aggregate went out.
-            bool win_issued = !p1.on;
-            {
-                bool failed = false;
-                unsigned spins = 0;
-                if (!win_issued) {
-                    unsigned arr = lds_load(&hdr[H_ARRIVED + (r & 7)]);
-                    while (arr != n_valid && __builtin_amdgcn_s_memrealtime() - t_pub < (unsigned long long)a.lb_trigger) {
-                        if (++spins >= err.spin_max) { err_set(err, 4u); failed = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        arr = lds_load(&hdr[H_ARRIVED + (r & 7)]);
-                    }
-                    if (!failed && arr != n_valid) { lookback_issue(a.status, a.gentot, p1.g, lane, win); win_issued = true; }
-                }
-                if (failed || !lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
-            }
+            if (!lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
             PFAC_STAMP(trace, 1);
             const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
-            const unsigned long long tot = bcast_last(wave_incl_scan(c));   // 15 tile counts of < 2^22 each
-            const bool mute = (a.fault & 1u) && blockIdx.x == 1 && r == 1;   // test knob: this batch is never published
-            if (!mute) publish_aggregate(a.status, g_cur, tot, lane);
-            t_pub = __builtin_amdgcn_s_memrealtime();
-            const Pend cur = {true, r, g_cur, tot, first, first + n_valid, c, mute};
-            // (c) round r-1 moves on: issue its look-back window now, finish it next iteration
-            if (p1.on) { if (!win_issued) lookback_issue(a.status, a.gentot, p1.g, lane, win); p2 = p1; p1.on = false; }
-            p1 = cur;
-            if (lds_load(&hdr[H_URGENT + (r & 7)]) != 0) {  // a wave overflowed its staging: it is waiting for this base
-                if (p2.on) { resolve(p2, &win); p2.on = false; }
-                resolve(p1, nullptr);
-                p1.on = false;
+            const unsigned incl = wave_incl_scan(c);        // 15 tile counts of < 2^22 each
+            const unsigned tot = bcast_last(incl);
+            const unsigned excl = incl - c;
+            // ---- place the tiles (lane c: the tile of compute wave c)
+            unsigned long long wb;
+            if (tot == 0) {
+                wb = ch_base + ch_used;                     // nothing to place (any valid index will do)
+            } else if (tot > a.chunk) {
+                // larger than a chunk (dense matches, or a small record array): an allocation of exactly this size
+                unsigned long long v = 0;
+                if (lane == 0) v = __hip_atomic_fetch_add(cursor, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                wb = (((unsigned long long)hi << 32) | lo) + excl;
+            } else if (ch_used + tot <= ch_size) {
+                wb = ch_base + ch_used + excl;
+                ch_used += tot;
+            } else {
+                // the batch continues in the spare chunk from the first tile that does not fit into this one
+                const unsigned long long fits = __ballot(ch_used + incl <= ch_size);    // a prefix of the lanes
+                const unsigned k = (unsigned)__popcll(fits);                            // first lane that moves (0..nc-1)
+                const unsigned off = __builtin_amdgcn_readlane(excl, k);
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)spare), hi = __builtin_amdgcn_readfirstlane((unsigned)(spare >> 32));
+                const unsigned long long nb = ((unsigned long long)hi << 32) | lo;
+                wb = (unsigned)lane < k ? ch_base + ch_used + excl : nb + (excl - off);
+                ch_base = nb;
+                ch_size = a.chunk;
+                ch_used = tot - off;
+                spare = order_chunk();
             }
+            local_total += tot;
+            const bool mute = (a.fault & 1u) && blockIdx.x == 1 && r == 1;   // test knob: the bases of this round never come
+            if (lane < nc) {
+                hdr[H_WBASE + (r & 7) * 32 + lane * 2] = (unsigned)wb;
+                hdr[H_WBASE + (r & 7) * 32 + lane * 2 + 1] = (unsigned)(wb >> 32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0 && !mute) lds_store(&hdr[H_READY + (r & 7)], r + 1);
+            if ((unsigned)lane < n_valid) a.tile_index[first + (unsigned)lane] = wb | ((unsigned long long)c << TIX_CNT_SHIFT);
 #ifdef PFAC_TRACE_BUILD
             if (trace) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = g_cur; }
 #endif
@@ -1036,11 +949,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             for (int k = 0; k + 1 < AHEAD; k++) g[k] = g[k + 1];
             g[AHEAD - 1] = g_new;
         }
-        if (p2.on) resolve(p2, &win);
-        if (p1.on) resolve(p1, nullptr);
-        // every count of this workgroup has been posted by now: report how many tiles were denser than the sparse
+        // every count of this workgroup has been posted by now: matches, and how many tiles were denser than the sparse
         // staging capacity (the host switches staging mode on it)
         if (lane == 0) {
+            if (local_total) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.ctl + CTL_TOTAL), local_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned ovf = lds_load(&hdr[H_OVF]);
             if (ovf) __hip_atomic_fetch_add(&a.ctl[CTL_OVF], ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1099,9 +1011,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         if (have_n1) issue_loads(t_n1, wB, hB);
     }
 
-    // pending[k]: the tile scanned k+1 rounds ago still sits in its staging buffer
-    bool have1 = false, have2 = false;
-    unsigned cnt1 = 0, cnt2 = 0, buf = 0;      // buf: staging buffer of the current round, (r % NBUF)
+    // pend_have[k]: the tile scanned k+1 rounds ago still sits in its staging buffer (pend_cnt[k] records)
+    bool pend_have[LAG];
+    unsigned pend_cnt[LAG], buf = 0;           // buf: staging buffer of the current round, (r % NBUF)
+#pragma unroll
+    for (int k = 0; k < LAG; k++) { pend_have[k] = false; pend_cnt[k] = 0; }
 
     // One round: w / hw hold this round's tile; they are refilled with the tile LOAD_DEPTH rounds ahead as soon as
     // their bytes sit in LDS.  Returns false after the wave's last tile.
@@ -1200,7 +1114,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #endif
         if (lane == 0) {
             hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
-            if (now) lds_store(&hdr[H_URGENT + (r & 7)], 1u);
             if (cnt > a.sparse_cap) atomicAdd(&hdr[H_OVF], 1u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             arrival = atomicAdd(&hdr[H_ARRIVED + (r & 7)], 1u);
@@ -1222,17 +1135,18 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                     copy_out(a, stage, (unsigned)cnt, base, lane);   // dense mode: staged, emitted at once
             }
         }
-        // ---- emit the tile of TWO rounds ago: its batch base has long been resolved (a tile without records has
-        // nothing to wait for: the coordinator stores the tile index)
-        if (have2 && cnt2 != 0) {
+        // ---- emit the tile of LAG rounds ago: its bases came when that round's last count was in (a tile without
+        // records has nothing to wait for: the coordinator stores the tile index)
+        if (pend_have[LAG - 1] && pend_cnt[LAG - 1] != 0) {
             unsigned long long base = 0;
-            const bool okb = record_base(r - 2, base);
+            const bool okb = record_base(r - LAG, base);
             PFAC_STAMP(trace, 9);
-            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, lane);
+            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, pend_cnt[LAG - 1], base, lane);
         }
         PFAC_STAMP(trace, 8);
-        have2 = have1; cnt2 = cnt1;
-        have1 = !now; cnt1 = (unsigned)cnt;
+#pragma unroll
+        for (int k = LAG - 1; k > 0; k--) { pend_have[k] = pend_have[k - 1]; pend_cnt[k] = pend_cnt[k - 1]; }
+        pend_have[0] = !now; pend_cnt[0] = (unsigned)cnt;
         buf = a.nbuf == 1 ? 0u : (buf + 1) % NBUF;
         if (LOAD_DEPTH == 1) {
             if (!more_far) return false;
@@ -1250,14 +1164,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         if (!round_body(wA, hA)) break;
         if (LOAD_DEPTH == 2 && !round_body(wB, hB)) break;
     }
-    // drain: the last two rounds' tiles (staged in buffers buf+1 [two rounds ago] and buf+2 [last round])
-    if (have2 && cnt2 != 0) {
-        unsigned long long base = 0;
-        if (record_base(r - 1, base)) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, cnt2, base, lane);
-    }
-    if (have1 && cnt1 != 0) {
-        unsigned long long base = 0;
-        if (record_base(r, base)) copy_out(a, stage0 + ((buf + 2) % NBUF) * a.stage_cap, cnt1, base, lane);
+    // drain: the tiles of the last LAG rounds (pend_have[k]: round r - k, staged in buffer (r - k) % NBUF)
+#pragma unroll
+    for (int k = LAG - 1; k >= 0; k--) {
+        if (pend_have[k] && pend_cnt[k] != 0) {
+            unsigned long long base = 0;
+            if (record_base(r - (unsigned)k, base))
+                copy_out(a, stage0 + ((buf + NBUF - 1 - k) % NBUF) * a.stage_cap, pend_cnt[k], base, lane);
+        }
     }
 }
 
@@ -1278,8 +1192,12 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         if (left + 1 == (blockDim.x >> 6)) {
             const unsigned done = __hip_atomic_fetch_add(&a.ctl[CTL_DONE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (done + 1 == gridDim.x) {
+                const unsigned long long tot = __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.ctl + CTL_TOTAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.ctl + CTL_CURSOR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.res[0] = (unsigned)tot; a.res[1] = (unsigned)(tot >> 32);
                 a.res[2] = __hip_atomic_load(&a.ctl[CTL_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a.res[3] = __hip_atomic_load(&a.ctl[CTL_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.res[4] = (unsigned)cur; a.res[5] = (unsigned)(cur >> 32);
             }
         }
     }
@@ -1370,57 +1288,96 @@ __device__ __forceinline__ unsigned long long match_hash(unsigned long long pos,
     return x * 0xBF58476D1CE4E5B9ull;
 }
 
-// Packed records: one wave per tile at a time; record i of tile t is word i of [tile_first[t], tile_first[t+1]).
-// Only records with index < n count (n <= total).
-__global__ void pfac_checksum_packed_kernel(const unsigned *rec, const unsigned long long *tile_first, unsigned long long n_tiles,
-                                            unsigned long long n, unsigned long long base, const int *idmap,
-                                            unsigned long long *out) {
+// Records are read through the tile index (the heap has gaps): tile t holds tix[t] >> 40 records from index
+// tix[t] & TIX_BASE_MASK on; records past the capacity of the array were never written.
+template <bool PACKED>
+__device__ __forceinline__ void heap_record(const void *rec, unsigned long long i, unsigned long long tile, unsigned &pos, unsigned &state) {
+    if (PACKED) {
+        const unsigned w = static_cast<const unsigned *>(rec)[i];
+        pos = (unsigned)(tile * WTILE) + (w & 0xFFFu);
+        state = w >> 12;
+    } else {
+        const pfac_record r = static_cast<const pfac_record *>(rec)[i];
+        pos = r.pos;
+        state = r.state;
+    }
+}
+
+// Order-independent checksum of all records: one wave per tile at a time.
+template <bool PACKED>
+__global__ void pfac_checksum_kernel(const void *rec, const unsigned long long *tix, unsigned long long n_tiles,
+                                     unsigned long long cap, unsigned long long base, const int *idmap, unsigned long long *out) {
     unsigned long long sum = 0;
     const int lane = threadIdx.x & (WAVE - 1);
     const unsigned long long wstride = (unsigned long long)gridDim.x * (blockDim.x >> 6);
     for (unsigned long long t = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < n_tiles; t += wstride) {
-        const unsigned long long lo = tile_first[t];
-        unsigned long long hi = tile_first[t + 1];
-        hi = hi < n ? hi : n;
-        for (unsigned long long i = lo + lane; i < hi; i += WAVE) {
-            const unsigned w = rec[i];
-            sum += match_hash(base + t * WTILE + (w & 0xFFFu), (unsigned)idmap[w >> 12]);
+        const unsigned long long e = tix[t], lo = e & TIX_BASE_MASK;
+        const unsigned cnt = (unsigned)(e >> TIX_CNT_SHIFT);
+        for (unsigned i = (unsigned)lane; i < cnt && lo + i < cap; i += WAVE) {
+            unsigned pos, st;
+            heap_record<PACKED>(rec, lo + i, t, pos, st);
+            sum += match_hash(base + pos, (unsigned)idmap[st]);
         }
     }
     sum = wave_sum64(sum);
     if (lane == 0) atomicAdd(out, sum);
 }
 
-// Packed -> wide: records [first, first + n) of the scan as pfac_record {pos relative to the scanned range, state}.
-__global__ void pfac_expand_kernel(const unsigned *rec, const unsigned long long *tile_first, unsigned long long n_tiles,
+// Heap -> one sorted pfac_record array, three small kernels: records per group of 64 tiles, exclusive scan of the
+// group sums (one block), copy.  Only consumers that want the flat sorted array pay for this.
+constexpr int XGROUP = 64;
+__global__ void pfac_tix_group_sum_kernel(const unsigned long long *tix, unsigned long long n_tiles, unsigned long long *gsum, unsigned n_groups) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const unsigned long long t = (unsigned long long)g * XGROUP + lane;
+    const unsigned c = t < n_tiles ? (unsigned)(tix[t] >> TIX_CNT_SHIFT) : 0u;
+    const unsigned long long sum = wave_sum64(c);
+    if (lane == 0) gsum[g] = sum;
+}
+__global__ void pfac_scan_groups_kernel(unsigned long long *gsum, unsigned n_groups) {      // ONE block of 1024 threads
+    __shared__ unsigned long long part[1024];
+    const unsigned per = (n_groups + 1023u) / 1024u;
+    const unsigned lo = threadIdx.x * per, hi = lo + per < n_groups ? lo + per : n_groups;
+    unsigned long long sum = 0;
+    for (unsigned i = lo; i < hi; i++) sum += gsum[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = acc; acc += v; }
+    }
+    __syncthreads();
+    unsigned long long acc = part[threadIdx.x];
+    for (unsigned i = lo; i < hi; i++) { const unsigned long long v = gsum[i]; gsum[i] = acc; acc += v; }
+}
+// records [first, first + n) of the sorted sequence -> out[0, n)
+template <bool PACKED>
+__global__ void pfac_expand_kernel(const void *rec, const unsigned long long *tix, unsigned long long n_tiles,
+                                   const unsigned long long *gpre, unsigned n_groups, unsigned long long cap,
                                    unsigned long long first, unsigned long long n, pfac_record *out) {
     const int lane = threadIdx.x & (WAVE - 1);
-    const unsigned long long wstride = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+    const unsigned g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const unsigned long long t = (unsigned long long)g * XGROUP + lane;
+    const unsigned long long e = t < n_tiles ? tix[t] : 0ull;
+    const unsigned c = (unsigned)(e >> TIX_CNT_SHIFT);
+    const unsigned long long lo = e & TIX_BASE_MASK;
+    const unsigned long long off = gpre[g] + (wave_incl_scan(c) - c);     // sorted index of the tile's first record (< 2^32 per group)
     const unsigned long long end = first + n;
-    for (unsigned long long t = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < n_tiles; t += wstride) {
-        unsigned long long lo = tile_first[t], hi = tile_first[t + 1];
-        lo = lo > first ? lo : first;
-        hi = hi < end ? hi : end;
-        for (unsigned long long i = lo + lane; i < hi; i += WAVE) {
-            const unsigned w = rec[i];
+    for (int j = 0; j < XGROUP; j++) {
+        const unsigned tc = __shfl(c, j, WAVE);
+        if (tc == 0) continue;
+        const unsigned long long tlo = __shfl(lo, j, WAVE), toff = __shfl(off, j, WAVE);
+        if (toff >= end || toff + tc <= first) continue;
+        for (unsigned i = (unsigned)lane; i < tc; i += WAVE) {
+            const unsigned long long k = toff + i;
+            if (k < first || k >= end || tlo + i >= cap) continue;
             pfac_record o;
-            o.pos = (unsigned)(t * WTILE) + (w & 0xFFFu);
-            o.state = w >> 12;
-            out[i - first] = o;
+            heap_record<PACKED>(rec, tlo + i, (unsigned long long)g * XGROUP + j, o.pos, o.state);
+            out[k - first] = o;
         }
     }
-}
-
-__global__ void pfac_checksum_kernel(const pfac_record *rec, unsigned long long n, unsigned long long base,
-                                     const int *idmap, unsigned long long *out) {
-    unsigned long long sum = 0;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const pfac_record r = rec[i];
-        sum += match_hash(base + r.pos, (unsigned)idmap[r.state]);
-    }
-    sum = wave_sum64(sum);
-    if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(out, sum);
 }
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -1466,22 +1423,24 @@ struct Slot {
     uint64_t input_cap = 0;
     void *d_records = nullptr;            // record_cap x 8 bytes: holds either record format
     uint64_t record_cap = 0;
-    unsigned long long *d_tile_first = nullptr;   // packed scans: first record index of every tile (+ the total)
+    unsigned long long *d_tile_index = nullptr;   // per tile of the last scan: first record | count << 40
     uint64_t tile_cap = 0;
+    unsigned long long *d_gsum = nullptr; // scratch of the expand path: record prefix per group of 64 tiles
+    uint64_t gsum_cap = 0;
     pfac_record *d_wide = nullptr;        // scratch of pfac_records_d2h: packed records expanded on the device
     uint64_t wide_cap = 0;
     bool last_packed = false;             // record format of the slot's last scan
     const void *last_records = nullptr;   // ... and where it wrote
-    unsigned *d_ctl = nullptr;            // TWO control buffers (16 control words + the status array each), used alternately:
+    unsigned *d_ctl = nullptr;            // TWO control headers (ticket counters, flags, heap cursor), used alternately:
     unsigned *d_ctlbuf[2] = {nullptr, nullptr};   // a scan zeroes the other one for the scan after it
-    uint64_t clean[2] = {0, 0};           // status words (from 0) of each buffer known to be zero
-    int flip = 0;                         // buffer of the next scan
-    uint64_t status_cap = 0;              // status words per buffer
-    unsigned *h_ctl = nullptr;            // pinned, device-visible: [0..1] total, [2] err (written by the kernel), [4..5] checksum
+    bool clean[2] = {false, false};       // header known to be zero
+    int flip = 0;                         // header of the next scan
+    unsigned *h_ctl = nullptr;            // pinned, device-visible: [0..1] matches, [2] err, [3] dense tiles, [4..5] heap
+                                          // records used (written by the kernel), [8..9] checksum
     unsigned *d_res = nullptr;            // device-side address of h_ctl
     unsigned long long *d_sum = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    uint64_t last_cap = 0, last_tiles = 0, last_total = 0;
+    uint64_t last_cap = 0, last_tiles = 0, last_total = 0, last_used = 0;
     bool scanned = false, pending = false, last_dense = false;
     unsigned long long *d_dbg = nullptr;  // PFAC_TRACE_BUILD + PFAC_TRACE
 };
@@ -1521,7 +1480,7 @@ struct pfac_ctx {
     int l2f_mode = 0, n_child = 0, bm2_rows = 0, sh_bm2 = 0;
     unsigned child0 = 0, child1 = 0;
     // tuning / test knobs, read from the environment ONCE, when a table is installed
-    unsigned lb_trigger = 300, spin_max = SPIN_MAX, fault = 0, ticket_ways_knob = 0;
+    unsigned spin_max = SPIN_MAX, fault = 0, ticket_ways_knob = 0;
     std::string trace_file;
     std::string err;
     std::mutex mu;
@@ -1550,35 +1509,27 @@ int check_slot(pfac_ctx *ctx, int slot) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int ensure_status(pfac_ctx *ctx, Slot &s, uint64_t n_words) {
-    if (s.d_ctl && s.status_cap >= n_words) return PFAC_OK;
-    if (s.d_ctl) {
-        HIP_TRY(ctx, hipStreamSynchronize(s.stream));            // a running scan may still be zeroing the old buffers
-        HIP_TRY(ctx, hipFree(s.d_ctl));
-    }
-    s.d_ctl = nullptr;
-    uint64_t cap = n_words < 4096 ? 4096 : n_words + n_words / 4;
-    const size_t region = align_up(CTL_WORDS * 4 + cap * 8 + 16, 256);
-    HIP_TRY(ctx, hipMalloc((void **)&s.d_ctl, 2 * region));
-    // on the slot's own stream: it is a non-blocking stream, a null-stream memset is not ordered before the scan that follows
-    HIP_TRY(ctx, hipMemsetAsync(s.d_ctl, 0, 2 * region, s.stream));
+constexpr size_t CTL_REGION = (CTL_WORDS * 4 + 255) / 256 * 256;
+
+int ensure_ctl(pfac_ctx *ctx, Slot &s) {
+    if (s.d_ctl) return PFAC_OK;
+    HIP_TRY(ctx, hipMalloc((void **)&s.d_ctl, 2 * CTL_REGION));
     s.d_ctlbuf[0] = s.d_ctl;
-    s.d_ctlbuf[1] = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(s.d_ctl) + region);
-    s.clean[0] = s.clean[1] = cap;
+    s.d_ctlbuf[1] = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(s.d_ctl) + CTL_REGION);
+    s.clean[0] = s.clean[1] = false;
     s.flip = 0;
-    s.status_cap = cap;
     return PFAC_OK;
 }
 
 int ensure_tiles(pfac_ctx *ctx, Slot &s, uint64_t n_entries) {
-    if (s.d_tile_first && s.tile_cap >= n_entries) return PFAC_OK;
-    if (s.d_tile_first) {
+    if (s.d_tile_index && s.tile_cap >= n_entries) return PFAC_OK;
+    if (s.d_tile_index) {
         HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-        HIP_TRY(ctx, hipFree(s.d_tile_first));
-        s.d_tile_first = nullptr;
+        HIP_TRY(ctx, hipFree(s.d_tile_index));
+        s.d_tile_index = nullptr;
     }
     const uint64_t cap = n_entries < 4096 ? 4096 : n_entries + n_entries / 4;
-    HIP_TRY(ctx, hipMalloc((void **)&s.d_tile_first, cap * 8));
+    HIP_TRY(ctx, hipMalloc((void **)&s.d_tile_index, cap * 8));
     s.tile_cap = cap;
     return PFAC_OK;
 }
@@ -1671,7 +1622,6 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->sh_bm2 = ctx->shared_bytes;
     if (ctx->l2f_mode == 2) ctx->shared_bytes += ctx->bm2_rows * 32;
     // knobs (tuning and tests), read once per table install
-    ctx->lb_trigger = (unsigned)env_int("PFAC_LBD", 300);
     ctx->spin_max = (unsigned)env_int("PFAC_SPIN_MAX", (int)SPIN_MAX);
     if (ctx->spin_max < 64) ctx->spin_max = 64;
     ctx->fault = (unsigned)env_int("PFAC_FAULT", 0);
@@ -1824,7 +1774,8 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
         if (s.d_input) (void)hipFree(s.d_input);
         if (s.d_records) (void)hipFree(s.d_records);
         if (s.d_ctl) (void)hipFree(s.d_ctl);
-        if (s.d_tile_first) (void)hipFree(s.d_tile_first);
+        if (s.d_tile_index) (void)hipFree(s.d_tile_index);
+        if (s.d_gsum) (void)hipFree(s.d_gsum);
         if (s.d_wide) (void)hipFree(s.d_wide);
         if (s.d_dbg) (void)hipFree(s.d_dbg);
         if (s.d_sum) (void)hipFree(s.d_sum);
@@ -1935,36 +1886,30 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     s.last_cap = capacity;
     s.scanned = true;
     s.pending = true;
-    s.h_ctl[0] = s.h_ctl[1] = s.h_ctl[2] = 0;          // result words (the kernel writes them through the host mapping)
+    for (int i = 0; i < 6; i++) s.h_ctl[i] = 0;        // result words (the kernel writes them through the host mapping)
     // staging mode of this launch (see pfac_scan_finish for the adaptation)
     const bool dense = ctx->dense && ctx->stage_cap_d;
     const int wpb = dense ? ctx->waves_per_block_d : ctx->waves_per_block;
     const int lds_bytes = dense ? ctx->lds_bytes_d : ctx->lds_bytes;
     s.last_dense = dense;
     s.last_tiles = n_tiles;
-    s.h_ctl[3] = 0;
-    // ticket + one look-back word per batch (+ the tickets taken ahead by every workgroup) must start at zero.  The
-    // slot has two control buffers: every scan zeroes, in its own prologue, what the next scan needs in the other
-    // one, so back-to-back scans of similar size need no memset; anything else falls back to one.
-    const uint64_t n_batches = (n_tiles + wpb - 2) / (wpb - 1);
-    const uint64_t n_status = n_batches + 6ull * ctx->grid_blocks + 8;       // + the tickets every workgroup draws past the end
-    const uint64_t need = n_status * (uint64_t)ST_STRIDE + (n_status / GEN + 2) * (uint64_t)GT_STRIDE;   // u64 words
-    rc = ensure_status(ctx, s, need);
+    s.last_packed = ctx->packed;
+    s.last_records = d_records;
+    // The control header (ticket counters, flags, heap cursor) must start at zero.  The slot has two: every scan
+    // zeroes, in its own prologue, the other one for the scan after it, so back-to-back scans need no memset.
+    rc = ensure_ctl(ctx, s);
     if (rc) return rc;
     rc = ensure_tiles(ctx, s, n_tiles + 1);
     if (rc) return rc;
-    s.last_packed = ctx->packed;
-    s.last_records = d_records;
-    if (n_tiles == 0) HIP_TRY(ctx, hipMemsetAsync(s.d_tile_first, 0, 8, s.stream));   // total = 0
+    const uint64_t n_batches = (n_tiles + wpb - 2) / (wpb - 1);
     unsigned *const cur = s.d_ctlbuf[s.flip], *const nxt = s.d_ctlbuf[1 - s.flip];
-    if (n_tiles > 0 && s.clean[s.flip] < need)
-        HIP_TRY(ctx, hipMemsetAsync(cur, 0, CTL_WORDS * 4 + align_up(need * 8, 16), s.stream));
+    if (n_tiles > 0 && !s.clean[s.flip]) HIP_TRY(ctx, hipMemsetAsync(cur, 0, CTL_REGION, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.ev0, s.stream));
     if (n_tiles > 0) {
         ScanArgs a;
         a.in = in; a.n_owned = n_owned; a.n_avail = n_avail;
         a.out = d_records; a.out_cap = capacity;
-        a.tile_first = s.d_tile_first;
+        a.tile_index = s.d_tile_index;
         a.packed = ctx->packed ? 1u : 0u;
         a.l2f_mode = ctx->l2f_mode; a.child0 = ctx->child0; a.child1 = ctx->child1; a.n_child = ctx->n_child;
         a.bm2 = ctx->d_bm2; a.bm2_rows = ctx->bm2_rows; a.sh_bm2 = ctx->sh_bm2;
@@ -1982,17 +1927,14 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;
         a.root_state = ctx->root_state;
-        a.lb_trigger = ctx->lb_trigger;
         a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
         a.nbuf = dense ? 1u : (unsigned)NBUF;
         a.sparse_cap = ctx->stage_cap;
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = cur;
         a.zero_next = reinterpret_cast<uint4 *>(nxt);
-        a.zero_vec = (unsigned)((CTL_WORDS * 4 + align_up(need * 8, 16)) / 16);
+        a.zero_vec = (unsigned)(CTL_REGION / 16);
         a.res = s.d_res;
-        a.status = reinterpret_cast<unsigned long long *>(cur + CTL_WORDS);
-        a.gentot = a.status + n_status * (uint64_t)ST_STRIDE;
         a.dbg = nullptr;
 #ifdef PFAC_TRACE_BUILD
         if (!ctx->trace_file.empty()) {
@@ -2005,10 +1947,16 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
         a.ticket_ways = grid < TICKET_WAYS ? (unsigned)grid : TICKET_WAYS;
         if (ctx->ticket_ways_knob >= 1 && ctx->ticket_ways_knob < a.ticket_ways) a.ticket_ways = ctx->ticket_ways_knob;
+        // heap chunk: 1/32 of an even share of the record array per workgroup -- the current and the spare chunk of
+        // every workgroup can stay unfilled at the end, i.e. at most 1/16 of the capacity; record arrays too small for
+        // chunks of 1024 records get exact allocations (one atomic per batch)
+        uint64_t chunk = (capacity / (32 * grid)) & ~3ull;
+        if (chunk > (1u << 22)) chunk = 1u << 22;
+        a.chunk = chunk >= 1024 ? (unsigned)chunk : 0u;
         void *kargs[] = {&a};
         HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
-        s.clean[s.flip] = 0;                   // used by this scan
-        s.clean[1 - s.flip] = need;            // zeroed by this scan
+        s.clean[s.flip] = false;               // used by this scan
+        s.clean[1 - s.flip] = true;            // zeroed by this scan
         s.flip = 1 - s.flip;
     }
     HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
@@ -2027,6 +1975,7 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     s.pending = false;
     const uint64_t total = ((uint64_t)s.h_ctl[1] << 32) | s.h_ctl[0];
     s.last_total = total;
+    s.last_used = ((uint64_t)s.h_ctl[5] << 32) | s.h_ctl[4];
     if (n_matches) *n_matches = total;
 #ifdef PFAC_TRACE_BUILD
     if (s.d_dbg && !ctx->trace_file.empty()) {
@@ -2037,7 +1986,7 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     }
 #endif
     if (s.h_ctl[2] != 0) {
-        s.clean[0] = s.clean[1] = 0;           // whatever state the control buffers are in: zero them before the next scan
+        s.clean[0] = s.clean[1] = false;       // whatever state the control headers are in: zero them before the next scan
         return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a timeout (flags " + std::to_string(s.h_ctl[2]) +
                                           ": 1 look-back, 4 arrivals, 8 record base, 16 batch ring)");
     }
@@ -2049,7 +1998,9 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
         if (!ctx->dense && ovf * 4 > s.last_tiles) ctx->dense = true;
         else if (ctx->dense && ovf * 16 < s.last_tiles) ctx->dense = false;
     }
-    if (total > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "more matches than record capacity");
+    if (s.last_used > s.last_cap)
+        return fail(ctx, PFAC_E_OVERFLOW, "record array too small: " + std::to_string(total) + " matches need " +
+                                              std::to_string(s.last_used) + " records of capacity (pfac_scan_capacity_hint)");
     return PFAC_OK;
 }
 
@@ -2064,29 +2015,53 @@ int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms) {
     return PFAC_OK;
 }
 
-// Packed records [first, first+n) of the slot's last scan -> pfac_record at d_out (device), on the slot's stream.
+// Records [first, first+n) of the slot's last scan, in (position, pattern length) order -> pfac_record at d_out
+// (device), on the slot's stream: prefix over the tile index, then a copy out of the heap.
 static int expand_records(pfac_ctx *ctx, Slot &s, const void *src, uint64_t first, uint64_t n, pfac_record *d_out) {
-    if (n == 0) return PFAC_OK;
-    if (!s.last_packed) {
-        HIP_TRY(ctx, hipMemcpyAsync(d_out, static_cast<const pfac_record *>(src) + first, n * sizeof(pfac_record),
-                                    hipMemcpyDeviceToDevice, s.stream));
-        return PFAC_OK;
+    if (n == 0 || s.last_tiles == 0) return PFAC_OK;
+    const unsigned n_groups = (unsigned)((s.last_tiles + XGROUP - 1) / XGROUP);
+    if (n_groups > s.gsum_cap) {
+        if (s.d_gsum) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_gsum)); s.d_gsum = nullptr; }
+        const uint64_t cap = n_groups < 4096 ? 4096 : n_groups + n_groups / 4;
+        HIP_TRY(ctx, hipMalloc((void **)&s.d_gsum, cap * 8));
+        s.gsum_cap = cap;
     }
-    const uint64_t want = (s.last_tiles + 3) / 4;
-    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-    hipLaunchKernelGGL(pfac_expand_kernel, dim3(grid), dim3(256), 0, s.stream, static_cast<const unsigned *>(src),
-                       s.d_tile_first, (unsigned long long)s.last_tiles, (unsigned long long)first, (unsigned long long)n, d_out);
+    const unsigned gblocks = (n_groups + 3) / 4;           // four waves (groups) per 256-thread block
+    hipLaunchKernelGGL(pfac_tix_group_sum_kernel, dim3(gblocks), dim3(256), 0, s.stream, s.d_tile_index,
+                       (unsigned long long)s.last_tiles, s.d_gsum, n_groups);
+    hipLaunchKernelGGL(pfac_scan_groups_kernel, dim3(1), dim3(1024), 0, s.stream, s.d_gsum, n_groups);
+    if (s.last_packed)
+        hipLaunchKernelGGL(pfac_expand_kernel<true>, dim3(gblocks), dim3(256), 0, s.stream, src, s.d_tile_index,
+                           (unsigned long long)s.last_tiles, s.d_gsum, n_groups, (unsigned long long)s.last_cap,
+                           (unsigned long long)first, (unsigned long long)n, d_out);
+    else
+        hipLaunchKernelGGL(pfac_expand_kernel<false>, dim3(gblocks), dim3(256), 0, s.stream, src, s.d_tile_index,
+                           (unsigned long long)s.last_tiles, s.d_gsum, n_groups, (unsigned long long)s.last_cap,
+                           (unsigned long long)first, (unsigned long long)n, d_out);
     HIP_TRY(ctx, hipGetLastError());
     return PFAC_OK;
 }
 
-int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles) {
+int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles, uint64_t *used) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "no scan yet");
     if (packed) *packed = s.last_packed ? 1 : 0;
     if (n_tiles) *n_tiles = s.last_tiles;
+    if (used) *used = s.last_used;
+    return PFAC_OK;
+}
+
+int pfac_scan_capacity_hint(pfac_ctx *ctx, int slot, uint64_t *capacity) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    Slot &s = ctx->slots[slot];
+    if (!s.scanned || !capacity) return fail(ctx, PFAC_E_STATE, "pfac_scan_capacity_hint: no finished scan");
+    // what the finished scan used (+ 1/8: a larger array means larger chunks, i.e. more unfilled space at the end)
+    // and a floor from the match count
+    const uint64_t a = s.last_used + s.last_used / 8, b = s.last_total + s.last_total / 4;
+    *capacity = (a > b ? a : b) + 65536;
     return PFAC_OK;
 }
 
@@ -2110,11 +2085,6 @@ int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record
     if (n == 0) return PFAC_OK;
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!s.last_packed) {
-        HIP_TRY(ctx, hipMemcpyAsync(host, static_cast<const pfac_record *>(src) + first, n * sizeof(pfac_record),
-                                    hipMemcpyDeviceToHost, s.stream));
-        return PFAC_OK;
-    }
     if (n > s.wide_cap) {
         if (s.d_wide) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_wide)); s.d_wide = nullptr; s.wide_cap = 0; }
         HIP_TRY(ctx, hipMalloc((void **)&s.d_wide, n * sizeof(pfac_record)));
@@ -2126,17 +2096,18 @@ int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record
     return PFAC_OK;
 }
 
-int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n,
-                            uint64_t *host_tile_first) {
+int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n_words,
+                            uint64_t *host_tile_index) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     const void *src = d_records ? d_records : s.d_records;
     if (!s.scanned || !s.last_packed) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h_packed: the slot's last scan did not produce packed records");
-    if (!src || (!host_words && n) || !host_tile_first) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: null buffer");
+    if (!src || (!host_words && n_words) || !host_tile_index) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: null buffer");
+    if (n_words > s.last_cap) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: more words than the record array holds");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (n) HIP_TRY(ctx, hipMemcpyAsync(host_words, src, n * 4, hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(ctx, hipMemcpyAsync(host_tile_first, s.d_tile_first, (s.last_tiles + 1) * 8, hipMemcpyDeviceToHost, s.stream));
+    if (n_words) HIP_TRY(ctx, hipMemcpyAsync(host_words, src, n_words * 4, hipMemcpyDeviceToHost, s.stream));
+    if (s.last_tiles) HIP_TRY(ctx, hipMemcpyAsync(host_tile_index, s.d_tile_index, s.last_tiles * 8, hipMemcpyDeviceToHost, s.stream));
     return PFAC_OK;
 }
 
@@ -2159,19 +2130,20 @@ int pfac_records_checksum(pfac_ctx *ctx, int slot, const void *d_records, uint64
     if (n && !s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_checksum without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(s.d_sum, 0, 16, s.stream));
-    if (n && s.last_packed) {
-        hipLaunchKernelGGL(pfac_checksum_packed_kernel, dim3(1024), dim3(256), 0, s.stream, static_cast<const unsigned *>(src),
-                           s.d_tile_first, (unsigned long long)s.last_tiles, (unsigned long long)n, (unsigned long long)base,
-                           ctx->d_idmap, s.d_sum);
-        HIP_TRY(ctx, hipGetLastError());
-    } else if (n) {
-        hipLaunchKernelGGL(pfac_checksum_kernel, dim3(1024), dim3(256), 0, s.stream, static_cast<const pfac_record *>(src),
-                           (unsigned long long)n, (unsigned long long)base, ctx->d_idmap, s.d_sum);
+    if (n && s.last_tiles) {
+        if (s.last_packed)
+            hipLaunchKernelGGL(pfac_checksum_kernel<true>, dim3(1024), dim3(256), 0, s.stream, src, s.d_tile_index,
+                               (unsigned long long)s.last_tiles, (unsigned long long)s.last_cap, (unsigned long long)base,
+                               ctx->d_idmap, s.d_sum);
+        else
+            hipLaunchKernelGGL(pfac_checksum_kernel<false>, dim3(1024), dim3(256), 0, s.stream, src, s.d_tile_index,
+                               (unsigned long long)s.last_tiles, (unsigned long long)s.last_cap, (unsigned long long)base,
+                               ctx->d_idmap, s.d_sum);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_ctl + 4, s.d_sum, 8, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_ctl + 8, s.d_sum, 8, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    *checksum = ((uint64_t)s.h_ctl[5] << 32) | s.h_ctl[4];
+    *checksum = ((uint64_t)s.h_ctl[9] << 32) | s.h_ctl[8];
     return PFAC_OK;
 }
 
@@ -2251,10 +2223,16 @@ int pfac_trace_table_compat(const pfac_thread_data *d, int device) {
     rc = pfac_table_upload(ctx, blob.data(), blob.size());
     if (!rc) rc = pfac_slot_reserve(ctx, 0, N, cap);
     if (!rc && N) rc = pfac_slot_h2d(ctx, 0, d->input_string, N, 0);
-    for (int attempt = 0; !rc && attempt < 2; attempt++) {
+    for (int attempt = 0; !rc && attempt < 4; attempt++) {
         rc = pfac_scan_async(ctx, 0, nullptr, N, N, nullptr, 0);
         if (!rc) rc = pfac_scan_finish(ctx, 0, &n);
-        if (rc == PFAC_E_OVERFLOW && attempt == 0) { cap = n; rc = pfac_slot_reserve(ctx, 0, N, cap); continue; }
+        if (rc == PFAC_E_OVERFLOW && attempt < 3) {
+            uint64_t hint = 0;
+            rc = pfac_scan_capacity_hint(ctx, 0, &hint);
+            cap = hint > 2 * cap ? hint : 2 * cap;
+            if (!rc) rc = pfac_slot_reserve(ctx, 0, N, cap);
+            continue;
+        }
         break;
     }
     if (!rc) {

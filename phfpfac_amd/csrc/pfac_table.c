@@ -566,20 +566,22 @@ static inline char *put_uint(char *p, uint64_t v, int min_width) {
     return p;
 }
 
-/* Where the records come from: wide pfac_record, or the compact device form (32-bit words + per-tile first index). */
+/* Where the records come from: a sorted pfac_record array, or the compact device form (heap of 32-bit words + the
+ * ordered tile index; tile_pre[t] = records of the tiles before t, tile_pre[n_tiles] = all). */
 typedef struct {
     const pfac_record *rec;
     const uint32_t *words;
-    const uint64_t *tile_first;
+    const uint64_t *tile_index;
+    const uint64_t *tile_pre;
     uint64_t n_tiles;
 } rec_src;
 
-/* tile of packed record k: the t with tile_first[t] <= k < tile_first[t+1] (empty tiles skipped) */
+/* tile of record k of the sorted sequence: the t with tile_pre[t] <= k < tile_pre[t+1] (empty tiles skipped) */
 static uint64_t tile_of(const rec_src *s, uint64_t k) {
-    uint64_t lo = 0, hi = s->n_tiles;               /* invariant: tile_first[lo] <= k < tile_first[hi] */
+    uint64_t lo = 0, hi = s->n_tiles;               /* invariant: tile_pre[lo] <= k < tile_pre[hi] */
     while (hi - lo > 1) {
         const uint64_t mid = lo + (hi - lo) / 2;
-        if (s->tile_first[mid] <= k) lo = mid; else hi = mid;
+        if (s->tile_pre[mid] <= k) lo = mid; else hi = mid;
     }
     return lo;
 }
@@ -593,9 +595,10 @@ static char *format_records(const rec_src *s, uint64_t k0, uint64_t k1, uint64_t
         uint64_t pos;
         uint32_t st;
         if (s->words) {
-            while (k >= s->tile_first[t + 1]) t++;
-            pos = base + t * PFAC_TILE_BYTES + PFAC_PACKED_POS(s->words[k]);
-            st = PFAC_PACKED_STATE(s->words[k]);
+            while (k >= s->tile_pre[t + 1]) t++;
+            const uint32_t w = s->words[PFAC_TIX_FIRST(s->tile_index[t]) + (k - s->tile_pre[t])];
+            pos = base + t * PFAC_TILE_BYTES + PFAC_PACKED_POS(w);
+            st = PFAC_PACKED_STATE(w);
         } else {
             pos = base + s->rec[k].pos;
             st = s->rec[k].state;
@@ -636,7 +639,7 @@ static int64_t emit_serial(FILE *f, const rec_src *s, uint64_t n, uint64_t base,
 
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap) {
     if (!file || (!rec && n)) return PFAC_E_ARG;
-    const rec_src s = {rec, NULL, NULL, 0};
+    const rec_src s = {rec, NULL, NULL, NULL, 0};
     return emit_serial((FILE *)file, &s, n, base, idmap);
 }
 
@@ -774,15 +777,23 @@ static int64_t emit_mt(FILE *f, const rec_src *src, uint64_t n, uint64_t base, c
 int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
                              int n_threads) {
     if (!file || (!rec && n)) return PFAC_E_ARG;
-    const rec_src s = {rec, NULL, NULL, 0};
+    const rec_src s = {rec, NULL, NULL, NULL, 0};
     return emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
 }
 
-int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_first, uint64_t n_tiles, uint64_t base,
+int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_index, uint64_t n_tiles, uint64_t base,
                          const int32_t *idmap, int n_threads) {
-    if (!file || !tile_first) return PFAC_E_ARG;
-    const uint64_t n = tile_first[n_tiles];
-    if (!words && n) return PFAC_E_ARG;
-    const rec_src s = {NULL, words, tile_first, n_tiles};
-    return emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
+    if (!file || (!tile_index && n_tiles)) return PFAC_E_ARG;
+    uint64_t *pre = (uint64_t *)malloc((size_t)(n_tiles + 1) * sizeof(uint64_t));
+    if (!pre) return PFAC_E_NOMEM;
+    uint64_t n = 0;
+    for (uint64_t t = 0; t < n_tiles; t++) { pre[t] = n; n += PFAC_TIX_COUNT(tile_index[t]); }
+    pre[n_tiles] = n;
+    int64_t rc = PFAC_E_ARG;
+    if (words || !n) {
+        const rec_src s = {NULL, words, tile_index, pre, n_tiles};
+        rc = emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
+    }
+    free(pre);
+    return rc;
 }

@@ -147,25 +147,32 @@ class GpuMatcher:
             self.sync(slot)
         return out
 
-    def scan_format(self, slot: int = 0) -> Tuple[bool, int]:
-        """(packed, n_tiles) of the slot's last scan: packed = 4-byte words + tile index on the device."""
-        pk, nt = C.c_int(0), C.c_uint64(0)
-        self._check(self._L.pfac_scan_format(self._ctx, slot, C.byref(pk), C.byref(nt)))
-        return bool(pk.value), nt.value
+    def scan_format(self, slot: int = 0) -> Tuple[bool, int, int]:
+        """(packed, n_tiles, used) of the slot's last scan: packed = 4-byte words in the record heap, n_tiles = entries
+        of the tile index, used = heap records in use (gaps included)."""
+        pk, nt, used = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.pfac_scan_format(self._ctx, slot, C.byref(pk), C.byref(nt), C.byref(used)))
+        return bool(pk.value), nt.value, used.value
+
+    def capacity_hint(self, slot: int = 0) -> int:
+        """A record capacity the slot's last scan fits (after an overflow)."""
+        c = C.c_uint64(0)
+        self._check(self._L.pfac_scan_capacity_hint(self._ctx, slot, C.byref(c)))
+        return c.value
 
     def expand_records(self, n: int, d_out, slot: int = 0, d_records=None, first: int = 0) -> None:
         """Records [first, first+n) of the slot's last scan as 8-byte ``pfac_record`` into the DEVICE buffer ``d_out``
         (asynchronous on the slot's stream) -- what the RCCL record gather sends."""
         self._check(self._L.pfac_records_expand(self._ctx, slot, _ptr(d_records), int(first), int(n), _ptr(d_out)))
 
-    def packed_to_host(self, n: int, slot: int = 0, d_records=None) -> Tuple[np.ndarray, np.ndarray]:
-        """The compact device form itself: (uint32 words [n], uint64 tile_first [n_tiles + 1])."""
-        _, nt = self.scan_format(slot)
-        words = np.empty(int(n), dtype=np.uint32)
-        tf = np.empty(nt + 1, dtype=np.uint64)
-        self._check(self._L.pfac_records_d2h_packed(self._ctx, slot, _ptr(d_records), words.ctypes.data, int(n), tf.ctypes.data))
+    def packed_to_host(self, slot: int = 0, d_records=None) -> Tuple[np.ndarray, np.ndarray]:
+        """The compact device form itself: (uint32 heap words [used], uint64 tile index [n_tiles])."""
+        _, nt, used = self.scan_format(slot)
+        words = np.empty(int(used), dtype=np.uint32)
+        tix = np.empty(max(nt, 1), dtype=np.uint64)
+        self._check(self._L.pfac_records_d2h_packed(self._ctx, slot, _ptr(d_records), words.ctypes.data, int(used), tix.ctypes.data))
         self.sync(slot)
-        return words, tf
+        return words, tix[:nt]
 
     def checksum(self, n: int, base: int = 0, slot: int = 0, d_records=None) -> int:
         s = C.c_uint64(0)
@@ -177,10 +184,16 @@ class GpuMatcher:
         n_avail = n_owned if n_avail is None else n_avail
         self.scan_async(n_owned, n_avail, d_input=d_input, slot=slot)
         n, over = self.scan_finish(slot, allow_overflow=True)
-        if over:
-            self.reserve(slot, 0, n)
+        cap = 0
+        for _ in range(4):
+            if not over:
+                break
+            cap = max(self.capacity_hint(slot), 2 * cap)
+            self.reserve(slot, 0, cap)
             self.scan_async(n_owned, n_avail, d_input=d_input, slot=slot)
-            n, _ = self.scan_finish(slot)
+            n, over = self.scan_finish(slot, allow_overflow=True)
+        if over:
+            raise PfacError(PFAC_E_OVERFLOW, "record heap still too small after four attempts")
         return n
 
     def scan_bytes(self, data, n_owned: Optional[int] = None, slot: int = 0) -> np.ndarray:

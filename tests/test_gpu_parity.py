@@ -528,7 +528,8 @@ def test_rccl_path_single_rank(resolve):
             g.scan_async(hi - lo, end - lo, d_input=buf, d_records=rec_t, capacity=rec_t.numel())
             n, over = g.scan_finish(0)
             assert not over
-            assert g.scan_format(0) == (True, -(-(hi - lo) // TILE))      # compact words + tile index on the device
+            packed, n_tiles, used = g.scan_format(0)                      # compact words in a heap + tile index
+            assert packed and n_tiles == -(-(hi - lo) // 4096) and n <= used <= rec_t.numel()
             g.expand_records(n, wide_t, d_records=rec_t)                  # -> pfac_record, still on the device
             g.sync(0)
         counts = pdist.gather_counts(n, dev)
