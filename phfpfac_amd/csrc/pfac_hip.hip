@@ -88,6 +88,10 @@ constexpr int D1_STATE_BITS = 20;          // packed dense-row entry (FUSED): st
 constexpr int D1_N2_MAX = 2048;            // ... so at most this many depth-2 states (the entry stays positive)
 // the PHF tables (variant 0) follow the dense rows: SH_D1 + d1_rows * 1024; the 2-byte-prefix bitmap (bm2_rows x 32
 // bytes) sits at ScanArgs::sh_bm2, behind them
+#ifndef PFAC_L2F_UNROLL
+#define PFAC_L2F_UNROLL 1
+#endif
+constexpr int L2F_UNROLL = PFAC_L2F_UNROLL;  // survivors classified per trip of the level-2 lookup loop
 constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
 #ifndef PFAC_NBUF
@@ -1078,20 +1082,34 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                 keep[j] = root_final ? m1 : deep[j];
             } else {
                 // one lookup per survivor in the 2-byte-prefix bitmap (and, for a multi-edge root, in the
-                // depth-1-state-is-final table)
+                // depth-1-state-is-final table).  Per-lane loop, up to L2F_UNROLL survivors per trip: their lookups are
+                // independent chains of two LDS round trips, so a trip costs one chain, not four.
                 unsigned dm = 0, fm = 0;
-                for (unsigned mm = m1; mm; mm &= mm - 1) {
-                    const unsigned b = __ffs(mm) - 1;
-                    const unsigned b1 = tile[off + b + 1];
-                    unsigned row = 0, fin = 0;
-                    if (ROOT != 1) {
-                        const unsigned b0 = tile[off + b];
-                        row = b0 * 32u;
-                        fin = finl[b0];
+                const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
+                for (unsigned mm = m1; mm;) {
+                    unsigned b[L2F_UNROLL], win[L2F_UNROLL], v[L2F_UNROLL], fin[L2F_UNROLL];
+                    bool on[L2F_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < L2F_UNROLL; u++) {
+                        on[u] = mm != 0u;
+                        b[u] = on[u] ? (unsigned)__ffs(mm) - 1u : 0u;
+                        mm &= mm - 1u;                              // (0 stays 0)
+                        const unsigned p = off + b[u];
+                        const unsigned lo = t32[p >> 2], hi = t32[(p >> 2) + 1];
+                        win[u] = __builtin_amdgcn_alignbyte(hi, lo, p & 3u);   // bytes p .. p+3
                     }
-                    const unsigned v = bm2l[row + (b1 >> 3)];
-                    dm |= ((v >> (b1 & 7u)) & 1u) << b;
-                    fm |= fin << b;
+#pragma unroll
+                    for (int u = 0; u < L2F_UNROLL; u++) {
+                        const unsigned b0 = win[u] & 0xFFu, b1 = (win[u] >> 8) & 0xFFu;
+                        v[u] = bm2l[(ROOT == 1 ? 0u : b0 * 32u) + (b1 >> 3)];
+                        fin[u] = ROOT == 1 ? 0u : (unsigned)finl[b0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < L2F_UNROLL; u++) {
+                        const unsigned b1 = (win[u] >> 8) & 0xFFu;
+                        dm |= on[u] ? ((v[u] >> (b1 & 7u)) & 1u) << b[u] : 0u;
+                        fm |= on[u] ? fin[u] << b[u] : 0u;
+                    }
                 }
                 deep[j] = dm;
                 keep[j] = dm | (ROOT == 1 ? (root_final ? m1 : 0u) : fm);

@@ -1,36 +1,46 @@
-"""GPU diagnostic: per-round timestamps of the coordinator and of compute wave 0 (PFAC_TRACE)."""
+"""GPU diagnostic: per-round timestamps of the coordinator and of compute wave 0 (trace build: make -C phfpfac_amd/csrc trace).
+usage: trace_rounds.py <pattern fixture | nomatch1> [text|rand]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "trace.bin")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "gpurun_out", "trace.bin")
 os.environ["PFAC_TRACE"] = out
-os.environ["PFAC_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ab", "libpfac_hip_trace.so")   # make -C phfpfac_amd/csrc trace
+os.environ["PFAC_HIP_LIB"] = os.path.join(ROOT, "ab", "libpfac_hip_trace.so")
 import numpy as np, torch
 from phfpfac_amd import GpuMatcher, PfacTable
-DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
+DATA = os.path.join(ROOT, "tests", "golden", "data")
 para = open(os.path.join(DATA, "paragraph402"), "rb").read()
 N = 1 << 30
-pats = {"exp": open(os.path.join(DATA, "experimentpattern"), "rb").read(), "nomatch": b"\x01\x02\n"}[sys.argv[1] if len(sys.argv) > 1 else "exp"]
+name = sys.argv[1] if len(sys.argv) > 1 else "experimentpattern"
+kind = sys.argv[2] if len(sys.argv) > 2 else "text"
+path = os.path.join(DATA, name)
+if name.endswith(".gz"):
+    import gzip, tempfile
+    path = os.path.join(tempfile.mkdtemp(), name[:-3]); open(path, "wb").write(gzip.open(os.path.join(DATA, name), "rb").read())
+t = PfacTable.from_bytes(b"\x01\x02\n", 256) if name == "nomatch1" else PfacTable.from_file(path, 256)
 buf = torch.empty(N + 4096, dtype=torch.uint8, device="cuda:0")
-t = PfacTable.from_bytes(pats, 256)
 with GpuMatcher(0, 1) as g:
-    g.load_table(t); g.fill_tiled(buf, N, para); g.reserve(0, 0, N // 8)
+    g.load_table(t)
+    if kind == "rand": g.fill_random(buf, N, 0x5048465046414331)
+    else: g.fill_tiled(buf, N, para)
+    g.reserve(0, 0, N // 8)
     for _ in range(3):
-        g.scan_async(N, N, d_input=buf); g.scan_finish(0)
-    print("kernel ms", g.elapsed_ms(0))
+        g.scan_async(N, N, d_input=buf); n, _ = g.scan_finish(0)
+    print(name, kind, "kernel ms", g.elapsed_ms(0), "matches", n, g.info())
 d = np.fromfile(out, dtype=np.uint64).reshape(8, 64, 32).astype(np.int64)
 for b in (0, 3):
     x = d[b]
     t0 = x[0, 4] if x[0, 4] else x[0, 0]
     print(f"block {b}: times in us relative to first stamp; columns:")
-    print("  r | coord: start arrivals_done lookback_done batch | compute w0: top lds_written masks_done pass_done end base_ready")
-    for r in range(0, 40):
+    print("  r | coord: start arrivals_done placed batch | compute w0: top lds_written masks_done pass_done end base_ready")
+    for r in range(0, 24):
         if x[r, 0] == 0 and x[r, 4] == 0: break
         f = lambda v: f"{(v - t0) / 100:8.2f}" if v else "    -   "
         print(f"{r:3d} | {f(x[r,0])} {f(x[r,1])} {f(x[r,2])} {x[r,3]:7d} | {f(x[r,4])} {f(x[r,5])} {f(x[r,6])} {f(x[r,7])} {f(x[r,8])} {f(x[r,9])}")
-
-x = d[0]
-t0 = x[0, 4]
-print("block 0: per-wave pass_done (us) per round")
-for r in range(0, 16):
-    if x[r, 16] == 0: break
-    print(f"{r:3d} | " + " ".join(f"{(x[r,16+w]-t0)/100:7.2f}" if x[r,16+w] else "   -   " for w in range(15)))
+    # mean phase durations of compute wave 0 over rounds 4..40
+    rows = [x[r] for r in range(4, 60) if x[r, 4] and x[r + 1, 4]]
+    if rows:
+        ph = {"load wait + lds write": np.mean([r_[5] - r_[4] for r_ in rows]), "epoch + root/level-2": np.mean([r_[6] - r_[5] for r_ in rows]),
+              "compact + walk + stage": np.mean([r_[7] - r_[6] for r_ in rows]), "post + emit": np.mean([r_[8] - r_[7] for r_ in rows])}
+        per = np.mean(np.diff([x[r, 4] for r in range(4, 60) if x[r, 4]]))
+        print("  wave 0 mean phases (us):", {k: round(v / 100, 2) for k, v in ph.items()}, "round", round(per / 100, 2))
