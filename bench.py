@@ -1,40 +1,49 @@
 #!/usr/bin/env python3
 """bench.py -- input GB/s scanned by the PFAC hot path on N MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--bytes-per-gpu B]
 
-(Before the W warm-up steps an untimed settling phase scans until eight consecutive launches agree within 1.5 %: a cold
-GPU's first ~40 launches run up to 20 % slower while the clocks ramp.)
+N > 1 works from a bare command line (the parent spawns one fresh process per GPU before anything touches a GPU) and
+under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE are
+then already set and nothing is spawned).
 
-A "step" is one pass of the hot path over one batch of synthetic input that is ALREADY RESIDENT in
-HBM: run the scan kernel over this rank's shard (its control/look-back words were zeroed by the slot's previous
-scan; 1 GiB owned +
-max_pat_len-1 bytes of halo) and read back the exact match count; with N > 1 the per-rank counts of the K steps
-are all-gathered once, inside the timed region (the one exchange the sharded path needs, to place records).  Weak scaling: every rank owns
-1 GiB, so the global stream is N GiB.  The workload is BASELINE.json configs[1]: pattern file
-`experimentpattern`, input = the reference's `1M` text (402-byte period) tiled to 1 GiB, 1 stream per
-GPU, PHF width 256.  Rank 0 builds the table on the host (C) and broadcasts its image with RCCL.
+A "step" is one pass of the hot path over one batch of synthetic input that is ALREADY RESIDENT in HBM: run the scan
+kernel over this rank's shard (owned bytes + max_pat_len-1 bytes of halo) and read back the exact match count.  With
+N > 1 the per-rank counts of the K steps are all-gathered once, inside the timed region (the one exchange the sharded
+path needs).  Weak scaling: every rank owns the same number of bytes (default 1 GiB at N = 1 = BASELINE.json
+configs[1]; 4 GiB per GPU at N > 1 = configs[3]'s shard size).  Workload = pattern file `experimentpattern`, input =
+the reference's `1M` text (402-byte period) tiled to the shard size, 1 stream per GPU, PHF width 256.  Rank 0 builds
+the table on the host (C) and broadcasts its image with RCCL.
 
-One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
-  roofline     algorithmic bytes (1 B per input byte) / kernel time measured with HIP events on the
-               stream the kernel runs on, against the 8 TB/s HBM3E peak
-  cpu_baseline serial Aho-Corasick (oracle/ac_serial.c, the CHECKER, kind "port") timed on this
-               host, one core, on a bounded sample of the same workload (N = 1 only)
+Before the W warm-up steps an untimed settling phase scans until eight consecutive launches agree within 1.5 % (a cold
+GPU's first ~40 launches run up to 20 % slower while the clocks ramp); its length and the cold figure are reported in
+`config` (`settle_launches`, `cold_first20_gbs`).
+
+One JSON line is printed by rank 0 (contract in the task statement) with extra objects:
+  roofline         algorithmic bytes (1 B per input byte) / kernel time measured with HIP events on the stream the kernel
+                   runs on, against the 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch from the committed rocprofv3
+                   PMC passes when they were taken from this very kernel source (else null), `traffic_model` = input +
+                   records + tile index bytes computed from this run
+  cpu_baseline     serial Aho-Corasick (oracle/ac_serial.c, the CHECKER, kind "port") on ONE host core, bounded sample;
+                   cpu_baseline_pfac (the oracle's PFAC-on-CPU walk, one core) and cpu_baseline_threads (serial AC on
+                   all the cores this process may use) next to it (N = 1 only)
+  other_workloads  short passes of the other BASELINE configurations' pattern sets / inputs (N = 1 only)
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
 DATA = os.path.join(REPO, "tests", "golden", "data")
+KERNEL_SRC = os.path.join(REPO, "phfpfac_amd", "csrc", "pfac_hip.hip")
+PROFILE = os.path.join(REPO, "profiles", "r2_pmc_per_launch.json")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GIB = 1 << 30
 
@@ -47,6 +56,29 @@ WORKLOADS = {
     "rand1g_snort75k": ("bytefile_1000000byte.gz", "rand", "bytefile/1000000byte (75840 patterns, 542732 states, tables via L2) x splitmix64 random bytes, {size}/GPU"),
     "text1g_snort75k": ("bytefile_1000000byte.gz", "text", "bytefile/1000000byte (75840 patterns, 542732 states, tables via L2) x reference 1M text tiled to {size}/GPU"),
 }
+HEADLINE = "text1g_experimentpattern"
+
+
+def spawn_ranks(n, argv, extra_env=None):
+    """Run `argv` as n fresh child processes, one per GPU, with the torch.distributed environment of a single node
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT).  The parent never touches a GPU.
+    Rank 0's stdout is passed through; returns the worst exit code."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(argv, env=env, stdout=None if rank == 0 else subprocess.DEVNULL))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        worst = worst or rc
+    return worst
 
 
 def pattern_path(name, tmpdir):
@@ -65,13 +97,20 @@ def pattern_path(name, tmpdir):
     return p
 
 
-def cpu_baseline_threads(pat_path, kind, para, n_threads, seconds=8.0):
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_threads(pat_path, kind, para, n_threads, seconds=6.0):
     """The same serial Aho-Corasick scan on n_threads host threads, each over its own 32 MiB slice (plus halo) of
     the workload, repeated for a few seconds -- the all-cores figure next to the one-core baseline."""
+    import ctypes as C
     import threading
     from orc import Oracle, lib
     from phfpfac_amd.matcher import splitmix64_bytes, tiled_bytes
-    import ctypes as C
     L = lib()
     o = Oracle(pat_path, 1, 1)
     ac = L.ac_build(o.m)
@@ -97,11 +136,11 @@ def cpu_baseline_threads(pat_path, kind, para, n_threads, seconds=8.0):
             "sample": f"{sum(done)} scans of a 32 MiB slice on {n_threads} threads ({dt:.1f} s), serial Aho-Corasick full-DFA per thread"}
 
 
-def cpu_baseline(pat_path, kind, para, seconds=12.0):
+def cpu_baseline(pat_path, kind, para, seconds=10.0):
     """Serial Aho-Corasick on ONE host core over a bounded sample of the same workload."""
+    import ctypes as C
     from orc import Oracle, lib
     from phfpfac_amd.matcher import splitmix64_bytes, tiled_bytes
-    import ctypes as C
     L = lib()
     o = Oracle(pat_path, 1, 1)
     ac = L.ac_build(o.m)
@@ -124,35 +163,80 @@ def cpu_baseline(pat_path, kind, para, seconds=12.0):
                       f"full-DFA, {matches} matches/pass; host has {os.cpu_count()} logical cores"}
 
 
+def cpu_baseline_pfac(pat_path, kind, para, seconds=6.0):
+    """BASELINE.md's second CPU figure: PFAC itself on one core -- the oracle's walk from every start offset over the
+    dense trie (the bit-exact emitter the GPU records are checked against)."""
+    from orc import Oracle
+    from phfpfac_amd.matcher import splitmix64_bytes, tiled_bytes
+    o = Oracle(pat_path, 1, 1)
+    sample = 32 << 20
+    buf = tiled_bytes(sample, para) if kind == "text" else splitmix64_bytes(sample, 0x5048465046414331)
+    passes, t0, n = 0, time.perf_counter(), 0
+    while True:
+        pos, _ = o.scan_spec(buf, None)
+        n = int(pos.size)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or passes >= 64:
+            break
+    o.close()
+    return {"value": round(passes * sample / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} pass(es) over the first 32 MiB of the workload ({dt:.1f} s), PFAC walk from every offset "
+                      f"over the dense trie (oracle/pfac_oracle.c), records materialised, {n} matches/pass"}
+
+
+def committed_traffic():
+    """HBM bytes per headline launch from the committed rocprofv3 --pmc passes -- only when they were taken from this
+    very kernel source (tools/summarize_prof.py stores its sha256)."""
+    try:
+        prof = json.load(open(PROFILE))
+        src = hashlib.sha256(open(KERNEL_SRC, "rb").read()).hexdigest()
+        if prof.get("kernel_source_sha256") == src:
+            return prof.get("derived_hbm_bytes"), "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, profiles/r2_pmc_per_launch.json (same kernel source)"
+        return None, "profiles/r2_pmc_per_launch.json was taken from a different kernel source: not reported"
+    except (OSError, ValueError):
+        return None, "no committed PMC profile"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="text1g_experimentpattern", choices=sorted(WORKLOADS))
-    ap.add_argument("--bytes-per-gpu", type=int, default=GIB)
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--bytes-per-gpu", type=int, default=0, help="default: 1 GiB at --gpus 1, 4 GiB per GPU otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="(default now) also time the other workloads (short) and report them")
-    ap.add_argument("--no-extra", action="store_true", help="time the headline workload only")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="also report the CPU baseline on this many host threads")
+    ap.add_argument("--extra", action="store_true", help="(default at --gpus 1) also time the other workloads (short)")
+    ap.add_argument("--no-extra", action="store_true", help="time the named workload only")
+    ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-cores CPU baseline (default: usable cores, at most 32; 0: skip)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        # bare `python bench.py --gpus N`: one fresh process per GPU, started before this one has touched a GPU
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    if os.environ.get("PFAC_BENCH_SPAWN_TEST"):            # tests/test_dist_cpu.py: the spawner alone, no GPU
+        me = {"rank": os.environ["RANK"], "local_rank": os.environ["LOCAL_RANK"], "world": os.environ["WORLD_SIZE"],
+              "master": os.environ["MASTER_ADDR"] + ":" + os.environ["MASTER_PORT"], "argv": sys.argv[1:]}
+        with open(os.path.join(os.environ["PFAC_BENCH_SPAWN_TEST"], "rank%s.json" % me["rank"]), "w") as f:
+            json.dump(me, f)
+        print(json.dumps(me), flush=True)
+        return
+
+    import numpy as np
     import torch
     from phfpfac_amd import GpuMatcher, PfacTable
     from phfpfac_amd import dist as pdist
-    from phfpfac_amd.matcher import tiled_bytes
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the PFAC scan has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # PFAC_BENCH_FORCE_DIST=1 runs the RCCL code path (table broadcast, count all-gather) even with one rank
+    # PFAC_BENCH_FORCE_DIST=1 runs the RCCL code path (table broadcast, count all-gather, record gather) even with one rank
     use_dist = world > 1 or os.environ.get("PFAC_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
@@ -163,10 +247,10 @@ def main():
     import tempfile
     tmpdir = tempfile.mkdtemp()
     para = open(os.path.join(DATA, "paragraph402"), "rb").read()
-    per = args.bytes_per_gpu
+    per = args.bytes_per_gpu or (GIB if world == 1 else 4 * GIB)
     n_total = per * world
 
-    def run_workload(name, steps, warmup):
+    def run_workload(name, steps, warmup, headline):
         pat_name, kind, desc = WORKLOADS[name]
         desc = desc.format(size=("%d GiB" % (per >> 30)) if per % GIB == 0 else ("%d bytes" % per))
         ppath = pattern_path(pat_name, tmpdir)
@@ -189,12 +273,13 @@ def main():
             g.fill_random(buf, (n_avail + 7) // 8 * 8, 0x5048465046414331 + lo // 8)
         cap = max(n_owned // 8, 1 << 20)
         g.reserve(0, 0, cap)
-        n = g.scan_resident(n_owned, n_avail, d_input=buf)                 # sizes the record buffer, warms up
-        g.reserve(1, 0, max(cap, n))
+        n = g.scan_resident(n_owned, n_avail, d_input=buf)                 # sizes the record heap, warms up
+        _, _, used = g.scan_format(0)
+        g.reserve(1, 0, max(cap, used + used // 8))
         assert g.scan_resident(n_owned, n_avail, d_input=buf, slot=1) == n
-        # parity spot check (outside the timed region) on the FULL-SIZE launch itself: records are globally
-        # ordered, so the matches that start in the first 4 MiB are a prefix of the record array -- compare that
-        # prefix, record for record, with the CPU oracle run on the same bytes.
+        # parity spot check (outside the timed region) on the FULL-SIZE launch itself: in (position, length) order the
+        # matches that start in the first 4 MiB are a prefix of the record sequence -- compare that prefix, record for
+        # record, with the CPU oracle run on the same bytes.
         from orc import Oracle
         m = min(4 << 20, n_owned)
         host = buf[: min(n_avail, m + table.halo)].cpu().numpy()
@@ -204,7 +289,7 @@ def main():
         opos, oids = opos[keep], oids[keep]
         o.close()
         k = int(opos.size)
-        rec = g.records_to_host(min(n, k + 1))
+        rec = g.records_to_host(min(n, k + 1), slot=1)
         ok = n >= k and np.array_equal(rec["pos"][:k].astype(np.int64), opos) and \
             np.array_equal(table.idmap[rec["state"][:k]], oids) and (n == k or int(rec["pos"][k]) >= m)
         if not ok:
@@ -244,9 +329,9 @@ def main():
             return cnt
 
         # Clock settling (untimed, part of the setup): the first ~40 back-to-back launches on a cold GPU run up to 20 %
-        # slower than the steady state (tools/series.py: 0.37 -> 0.42 -> 0.352 ms, then flat) -- the governor ramping,
-        # not the kernel.  Keep scanning until eight consecutive launches agree within 1.5 % (at most 96 launches,
-        # ~40 ms), so that W warm-up + K timed steps measure the steady state a long-running job sees.
+        # slower than the steady state -- the governor ramping, not the kernel.  Keep scanning until eight consecutive
+        # launches agree within 1.5 % (at most 96 launches), so that W warm-up + K timed steps measure the steady state
+        # a long-running job sees.  Both the number of launches and the cold figure go into the JSON.
         settle = 0
         while settle < 96:
             step(settle)
@@ -256,6 +341,7 @@ def main():
                 if max(last) <= 1.015 * min(last):
                     break
         drain(exchange=False)                  # (ranks settle after different numbers of launches: no collective here)
+        cold_ms = float(np.mean(kern_ms[:20]))
         for k in range(warmup):
             step(k)
         drain()
@@ -280,24 +366,46 @@ def main():
             cnt_all = int(tot.item())
         else:
             cnt_all = cnt
-        info = g.info()
+        res = {"name": name, "desc": desc, "ppath": ppath, "kind": kind, "dt": dt, "kernel_ms": float(np.mean(kern_ms)),
+               "kernel_ms_min": float(np.min(kern_ms)), "matches": cnt_all, "matches_rank": cnt, "table": table,
+               "n_owned": n_owned, "n_avail": n_avail, "settle": settle, "cold_ms": cold_ms}
+        if headline:
+            # What a consumer of ONE ordered record stream pays on top of the scan, reported next to the timed value:
+            # heap -> sorted 8-byte records on the device (expand), and (N > 1) their ordered gather on rank 0.
+            _, n_tiles, used = g.scan_format(1)
+            wide = torch.empty(max(cnt, 1), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            g.expand_records(cnt, wide, slot=1)
+            g.sync(1)
+            res["expand_ms"] = (time.perf_counter() - t1) * 1e3
+            res["heap_used"] = used
+            res["n_tiles"] = n_tiles
+            if use_dist:
+                counts = pdist.gather_counts(cnt, dev)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                gathered = pdist.gather_records(wide, cnt, counts, dst=0)
+                torch.cuda.synchronize()
+                dist.barrier()
+                res["gather_ms"] = (time.perf_counter() - t1) * 1e3
+                res["gather_records"] = int(sum(counts))
+                del gathered
+            del wide
+        res["info"] = g.info()
         g.close()
         del buf
         torch.cuda.empty_cache()
-        k_avg = float(np.mean(kern_ms))
-        return {"name": name, "desc": desc, "ppath": ppath, "kind": kind, "dt": dt, "kernel_ms": k_avg,
-                "kernel_ms_min": float(np.min(kern_ms)), "matches": cnt_all, "info": info, "table": table,
-                "n_owned": n_owned}
+        return res
 
-    res = run_workload(args.workload, args.steps, args.warmup)
+    res = run_workload(args.workload, args.steps, args.warmup, True)
     value = n_total * args.steps / res["dt"] / 1e9
     achieved = res["n_owned"] / (res["kernel_ms"] * 1e-3) / 1e9
-    traffic = None
-    prof = os.path.join(REPO, "profiles", "r1_pmc_per_launch.json")
-    if args.workload == "text1g_experimentpattern" and per == GIB and os.path.exists(prof):
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/summarize_prof.py)
-        traffic = json.load(open(prof)).get("derived_hbm_bytes")
+    traffic, traffic_note = (None, "measured for the headline workload at 1 GiB only")
+    if args.workload == HEADLINE and per == GIB:
+        traffic, traffic_note = committed_traffic()
+    rec_bytes = 4 if res["table"].num_final <= (1 << 20) else 8
     out = {
         "metric": "input GB/s scanned", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 4),
@@ -307,28 +415,42 @@ def main():
                    "kernel_variant": res["info"]["variant"], "tile_bytes": res["info"]["tile_bytes"],
                    "grid_blocks": res["info"]["grid_blocks"], "lds_bytes": res["info"]["lds_bytes"],
                    "parallelism": f"input-sharded x{world}, halo {res['table'].halo} B",
-                   "matches_per_step": res["matches"], "parity": "records of the first 4 MiB per rank == CPU oracle, bit-exact"},
+                   "matches_per_step": res["matches"], "record_bytes": rec_bytes,
+                   "record_layout": "heap of compact records + ordered tile index (8 B per 4 KiB tile)",
+                   "parity": "records of the first 4 MiB per rank == CPU oracle, bit-exact",
+                   "settle_launches": res["settle"], "cold_first20_gbs": round(res["n_owned"] / (res["cold_ms"] * 1e-3) / 1e9, 1),
+                   "expand_ms": round(res["expand_ms"], 3),
+                   "expand_note": "heap -> one sorted pfac_record array on the device, outside the timed region (what an ordered consumer pays)",
+                   "multi_gpu_note": "N > 1 numbers exist only where the driver ran them (SCALE_rNN.json): the builder's box has one GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_note": "HBM bytes per launch (read incl. halo/tables + 8 B per match written), from profiles/r1_pmc_per_launch.json",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                     "traffic_model": res["n_avail"] + rec_bytes * res["matches_rank"] + 8 * res["n_tiles"],
+                     "traffic_model_note": "bytes one launch must move: input incl. halo + record bytes of this run's matches + tile index",
                      "kernel": "pfac_scan_kernel", "kernel_ms_avg": round(res["kernel_ms"], 4),
                      "kernel_ms_min": round(res["kernel_ms_min"], 4),
                      "algorithmic_bytes_per_launch": res["n_owned"]},
     }
-    if not args.no_extra:
+    if "gather_ms" in res:
+        out["config"]["gather_ms"] = round(res["gather_ms"], 3)
+        out["config"]["gather_note"] = f"ordered gather of {res['gather_records']} 8-byte records to rank 0 (send/recv over RCCL), outside the timed region"
+    if world == 1 and not args.no_extra:
         out["other_workloads"] = {}
         for name in sorted(WORKLOADS):
             if name == args.workload:
                 continue
-            r = run_workload(name, max(3, args.steps // 4), 1)
+            k = max(3, args.steps // 4)
+            r = run_workload(name, k, 1, False)
             out["other_workloads"][name] = {
-                "value_gbs": round(n_total * max(3, args.steps // 4) / r["dt"] / 1e9, 2),
+                "value_gbs": round(n_total * k / r["dt"] / 1e9, 2),
                 "kernel_gbs": round(r["n_owned"] / (r["kernel_ms"] * 1e-3) / 1e9, 2),
-                "matches_per_step": r["matches"], "kernel_variant": r["info"]["variant"]}
+                "frac_of_hbm_peak": round(r["n_owned"] / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "steps": k, "matches_per_step": r["matches"], "kernel_variant": r["info"]["variant"]}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(res["ppath"], res["kind"], para)
-        if args.cpu_threads > 1:
-            out["cpu_baseline_threads"] = cpu_baseline_threads(res["ppath"], res["kind"], para, args.cpu_threads)
+        out["cpu_baseline_pfac"] = cpu_baseline_pfac(res["ppath"], res["kind"], para)
+        nthr = min(usable_cores(), 32) if args.cpu_threads < 0 else args.cpu_threads
+        if nthr > 1:
+            out["cpu_baseline_threads"] = cpu_baseline_threads(res["ppath"], res["kind"], para, nthr)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -101,3 +101,24 @@ def test_shard_plan_properties():
                 lo2, hi2, end = shard_read_range(n, r, world, 227)
                 assert (lo2, hi2) == (lo, hi) and hi <= end <= min(n, hi + 227)
             assert prev == n
+
+
+def test_bench_spawns_one_process_per_gpu(tmp_path):
+    """`python bench.py --gpus 2` from a bare command line: the parent starts two fresh children with the
+    torch.distributed environment of one node (it never touches a GPU itself), passes rank 0's stdout through and
+    returns the worst exit code.  PFAC_BENCH_SPAWN_TEST makes the children report their environment instead of
+    benchmarking (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PFAC_BENCH_SPAWN_TEST"] = str(tmp_path)
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["rank"] == "0"         # only rank 0 prints to the parent's stdout
+    got = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    assert [g["rank"] for g in got] == ["0", "1"] and [g["local_rank"] for g in got] == ["0", "1"]
+    assert all(g["world"] == "2" and g["master"].startswith("127.0.0.1:") for g in got)
+    assert got[0]["master"] == got[1]["master"] and got[0]["argv"] == ["--gpus", "2", "--steps", "3"]
