@@ -76,11 +76,12 @@ constexpr int MAX_WAVES_PER_BLOCK = 16;     // 15 compute waves + the coordinato
 constexpr int LDS_TOTAL = 160 * 1024;
 constexpr int LDS_TABLE_MAX = 40 * 1024;   // PHF tables up to this size are staged in LDS (variant 0)
 
-// shared (per workgroup) LDS: root row, 8 pre-shifted root-flag tables, then the PHF tables (variant 0)
+// shared (per workgroup) LDS: root row, 8 pre-shifted flag tables (u16: root-edge flag << k | can-be-a-second-byte
+// flag << (k + 8)), then the PHF tables (variant 0)
 constexpr int SH_HDR = 0;                  // round rings (H_* below)
 constexpr int SH_S0 = SH_HDR + 2048;
 constexpr int SH_FTAB = SH_S0 + 256 * 4;
-constexpr int SH_D1IDX = SH_FTAB + 8 * 256; // 256 x u8: dense-row index of the depth-1 state reached on each root byte
+constexpr int SH_D1IDX = SH_FTAB + 8 * 256 * 2; // 256 x u8: dense-row index of the depth-1 state reached on each root byte
 constexpr int SH_FIN = SH_D1IDX + 256;     // 256 x u8: 1 where the depth-1 state reached on that root byte is final
 constexpr int SH_D1 = SH_FIN + 256;        // d1_rows dense rows int32[256] (the hot first-level transition rows)
 constexpr int D1_MAX = 32;                 // at most this many depth-1 states get a dense row (else none do)
@@ -155,6 +156,8 @@ struct ScanArgs {
     int n_child;                          // mode 1: 0 (nothing is ever deep), 1 or 2
     const unsigned char *bm2;             // mode 2: bit (b0 << 8 | b1) set iff a path b0 b1 leaves the root
     int bm2_rows, sh_bm2;                 // rows staged in LDS (256, or 1 = the root byte's row) at this LDS offset
+    const unsigned char *sec2;            // [256]: 1 where the byte is the second byte of some pattern (column OR of bm2)
+    int sec_filter;                       // ROOT == 0, mode 2: pre-filter the lookups with sec2 (no 1-byte patterns)
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
     unsigned nbuf;                        // staging buffers per wave: NBUF = emit NBUF-1 rounds late, 1 = emit at once (dense mode)
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
@@ -741,9 +744,11 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
 
 // Root test: 16-bit mask of the lane's 16 bytes that have an edge out of the root.
 //   ROOT == 1: exactly one such byte value -> exact SWAR compare, flags gathered with v_dot4
-//   ROOT == 0: one LDS lookup per byte in pre-shifted flag tables (table k holds flag << k)
+//   ROOT == 0: one LDS lookup per byte in pre-shifted flag tables (table k holds flag << k).  The same lookup
+//              answers a second question for free: bits 16..31 of the result = which of the 16 bytes can be the
+//              SECOND byte of a pattern at all (the cheap half of the level-2 filter).
 template <int ROOT>
-__device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned char *ftab, unsigned root_x4) {
+__device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned short *ftab, unsigned root_x4) {
     if (ROOT == 1) {
         unsigned nm[4];
 #pragma unroll
@@ -765,7 +770,8 @@ __device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned char
             fa |= ftab[k * 256 + ba];
             fb |= ftab[k * 256 + bb];
         }
-        return fa | (fb << 8);
+        // fa: bits 0..7 root flags of bytes 0..7, bits 8..15 their second-byte flags; fb: the same for bytes 8..15
+        return (fa & 0xFFu) | ((fb & 0xFFu) << 8) | ((fa & 0xFF00u) << 8) | ((fb & 0xFF00u) << 16);
     }
 }
 
@@ -790,7 +796,7 @@ template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW>
 __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem, const ErrCh &err) {
     unsigned *hdr = reinterpret_cast<unsigned *>(smem + SH_HDR);
     int *s0 = reinterpret_cast<int *>(smem + SH_S0);
-    unsigned char *ftab = smem + SH_FTAB;
+    unsigned short *ftab = reinterpret_cast<unsigned short *>(smem + SH_FTAB);
     unsigned char *finl = smem + SH_FIN;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -805,10 +811,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     for (int i = tid; i < H_WORDS; i += blockDim.x) hdr[i] = 0;
     for (int i = tid; i < 256; i += blockDim.x) {
         const int v = a.s0[i];
+        const bool sec2 = a.sec2[i] != 0;
         s0[i] = v;
         finl[i] = (unsigned)v < (unsigned)a.num_final ? (unsigned char)1 : (unsigned char)0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) ftab[k * 256 + i] = v >= 0 ? (unsigned char)(1u << k) : (unsigned char)0;
+        for (int k = 0; k < 8; k++) ftab[k * 256 + i] = (unsigned short)((v >= 0 ? 1u << k : 0u) | (sec2 ? 1u << (k + 8) : 0u));
     }
     unsigned char *d1idx_l = smem + SH_D1IDX;
     int *d1_l = reinterpret_cast<int *>(smem + SH_D1);
@@ -1055,7 +1062,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             const unsigned off = j * MSUB + lane * MLANE;
             const u32x4 lo16 = *reinterpret_cast<const u32x4 *>(tile + off);
             const u32x4 hi16 = *reinterpret_cast<const u32x4 *>(tile + off + 16);
-            const unsigned raw = root_mask<ROOT>(lo16, ftab, a.root_byte) | (root_mask<ROOT>(hi16, ftab, a.root_byte) << 16);
+            const unsigned rlo = root_mask<ROOT>(lo16, ftab, a.root_byte), rhi = root_mask<ROOT>(hi16, ftab, a.root_byte);
+            const unsigned raw = (rlo & 0xFFFFu) | (rhi << 16);
             unsigned m1 = raw;
             if (tile_base + WTILE > a.n_owned) {   // last tile only: offsets at or past n_owned start no walk
                 const unsigned long long g = tile_base + off;
@@ -1086,7 +1094,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                 // independent chains of two LDS round trips, so a trip costs one chain, not four.
                 unsigned dm = 0, fm = 0;
                 const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
-                for (unsigned mm = m1; mm;) {
+                unsigned cand = m1;
+                if (ROOT != 1 && a.sec_filter) {
+                    // multi-edge root without 1-byte patterns: only survivors whose NEXT byte can be a second byte at
+                    // all are looked up (flags of bytes 1..31 from the root test's own lookups, byte 32 = one more)
+                    const unsigned nx = *reinterpret_cast<const unsigned *>(tile + off + 32);
+                    const unsigned s32 = (ftab[nx & 0xFFu] >> 8) & 1u;
+                    cand = m1 & ((((rlo >> 16) | (rhi & 0xFFFF0000u)) >> 1) | (s32 << 31));
+                }
+                for (unsigned mm = cand; mm;) {
                     unsigned b[L2F_UNROLL], win[L2F_UNROLL], v[L2F_UNROLL], fin[L2F_UNROLL];
                     bool on[L2F_UNROLL];
 #pragma unroll
@@ -1495,7 +1511,7 @@ struct pfac_ctx {
     bool packed = true;                   // record format: 4-byte words + tile index (final states fit 20 bits), else 8-byte records
     // level-2 filter (ScanArgs::l2f_mode)
     unsigned char *d_bm2 = nullptr;       // 2-byte-prefix bitmap, 256 rows of 32 bytes
-    int l2f_mode = 0, n_child = 0, bm2_rows = 0, sh_bm2 = 0;
+    int l2f_mode = 0, n_child = 0, bm2_rows = 0, sh_bm2 = 0, sec_filter = 0;
     unsigned child0 = 0, child1 = 0;
     // tuning / test knobs, read from the environment ONCE, when a table is installed
     unsigned spin_max = SPIN_MAX, fault = 0, ticket_ways_knob = 0;
@@ -1611,7 +1627,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     if (fused && ctx->d1_rows == 0) ctx->shared_bytes += 1024;   // r[] of the depth-1 states by root byte
     // ---- level-2 filter: the 2-byte-prefix bitmap is built on the device from the uploaded tables; a single-edge
     // root with at most two grandchildren gets the bit-parallel form (their bytes), everything else the lookup form
-    if (!ctx->d_bm2) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bm2, 256 * 32));
+    if (!ctx->d_bm2) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bm2, 256 * 32 + 256));   // bitmap + the second-byte flags
     hipLaunchKernelGGL(pfac_build_bm2_kernel, dim3(256), dim3(256), 0, 0, ctx->d_s0, ctx->d_r, ctx->d_T, ctx->width_bit,
                        ctx->ht_size, reinterpret_cast<unsigned long long *>(ctx->d_bm2));
     HIP_TRY(ctx, hipGetLastError());
@@ -1620,9 +1636,19 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->bm2_rows = 256;
     ctx->n_child = 0;
     ctx->child0 = ctx->child1 = 0;
+    std::vector<unsigned char> bm2_host(256 * 32 + 256);
+    HIP_TRY(ctx, hipMemcpy(bm2_host.data(), ctx->d_bm2, 256 * 32, hipMemcpyDeviceToHost));
+    for (int c = 0; c < 256; c++) {                         // column OR: can byte c be a pattern's second byte?
+        unsigned char any = 0;
+        for (int b0 = 0; b0 < 256; b0++) any |= (unsigned char)(bm2_host[(size_t)b0 * 32 + (c >> 3)] >> (c & 7) & 1);
+        bm2_host[256 * 32 + c] = any;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_bm2 + 256 * 32, bm2_host.data() + 256 * 32, 256, hipMemcpyHostToDevice));
+    bool any_fin1 = false;                                  // a 1-byte pattern: its survivors are kept whatever follows
+    for (int i = 0; i < 256; i++) any_fin1 = any_fin1 || (s0_host[i] >= 0 && s0_host[i] < ctx->num_final);
+    ctx->sec_filter = (fan != 1 && !any_fin1 && !getenv("PFAC_NO_SECF")) ? 1 : 0;
     if (fan == 1) {
-        unsigned char row[32];
-        HIP_TRY(ctx, hipMemcpy(row, ctx->d_bm2 + (size_t)rb * 32, 32, hipMemcpyDeviceToHost));
+        const unsigned char *row = bm2_host.data() + (size_t)rb * 32;
         int nch = 0, ch[2] = {0, 0};
         for (int c = 0; c < 256; c++)
             if (row[c >> 3] >> (c & 7) & 1) { if (nch < 2) ch[nch] = c; nch++; }
@@ -1931,6 +1957,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.packed = ctx->packed ? 1u : 0u;
         a.l2f_mode = ctx->l2f_mode; a.child0 = ctx->child0; a.child1 = ctx->child1; a.n_child = ctx->n_child;
         a.bm2 = ctx->d_bm2; a.bm2_rows = ctx->bm2_rows; a.sh_bm2 = ctx->sh_bm2;
+        a.sec2 = ctx->d_bm2 + 256 * 32; a.sec_filter = ctx->sec_filter;
         a.spin_max = ctx->spin_max; a.fault = ctx->fault;
         a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T; a.T4 = ctx->d_T4;
         a.r_words = ctx->max_row; a.t_entries = ctx->ht_size;
