@@ -20,10 +20,11 @@
  *   - <streamnum> really is the number of pipeline slots per GPU: chunk k+1 is
  *     read and copied H2D while chunk k is scanned and chunk k-1's records
  *     return (the reference creates streams, main.cc:209, and never uses them);
- *   - results come back as compact ordered records, not as a dense
+ *   - results come back as compact records -- 4 bytes per match plus 8 bytes per
+ *     4 KiB of input (the tile index that orders them) -- not as a dense
  *     input_size x max_pat_len array (master_kernel.cu:235-236,428); an emitter
- *     thread writes finished chunks in input order while later ones are still
- *     being scanned, so memory stays bounded.
+ *     thread prints finished chunks straight from that form, in input order,
+ *     while later ones are still being scanned, so memory stays bounded.
  * There is no CPU matching path in this program: without a GPU it fails.
  *
  * Environment: PFAC_GPUS=n limits the number of GPUs used; PFAC_CHUNK_MB sets
@@ -45,7 +46,10 @@
 typedef struct {
     uint64_t base;          /* global offset of the chunk's first owned byte */
     uint64_t n_owned, n_avail;
-    pfac_record *rec;       /* host copy of the chunk's records */
+    pfac_record *rec;       /* host copy of the chunk's records: 8-byte form (automata beyond 2^20 final states) ... */
+    uint32_t *words;        /* ... or the compact form: record heap + tile index (pfac.h) */
+    uint64_t *tix;
+    uint64_t n_tiles;
     uint64_t n_rec;
     int done;               /* guarded by g_mu */
 } chunk_t;
@@ -151,9 +155,19 @@ static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap
     float ms = 0;
     if (pfac_scan_elapsed_ms(ctx, slot, &ms) == 0) w->kernel_ms += ms;
     c->n_rec = n;
-    c->rec = (pfac_record *)malloc((n ? n : 1) * sizeof(pfac_record));
-    if (!c->rec) return fail(w, NULL, PFAC_E_NOMEM, "out of host memory for records");
-    if ((rc = pfac_records_d2h(ctx, slot, NULL, c->rec, 0, n))) return fail(w, ctx, rc, "d2h");
+    int packed = 0;
+    uint64_t used = 0;
+    if ((rc = pfac_scan_format(ctx, slot, &packed, &c->n_tiles, &used))) return fail(w, ctx, rc, "format");
+    if (packed) {                                   /* 4 bytes per match over PCIe; the emitter prints from this form */
+        c->words = (uint32_t *)malloc((used ? used : 1) * sizeof(uint32_t));
+        c->tix = (uint64_t *)malloc((c->n_tiles ? c->n_tiles : 1) * sizeof(uint64_t));
+        if (!c->words || !c->tix) return fail(w, NULL, PFAC_E_NOMEM, "out of host memory for records");
+        if ((rc = pfac_records_d2h_packed(ctx, slot, NULL, c->words, used, c->tix))) return fail(w, ctx, rc, "d2h");
+    } else {
+        c->rec = (pfac_record *)malloc((n ? n : 1) * sizeof(pfac_record));
+        if (!c->rec) return fail(w, NULL, PFAC_E_NOMEM, "out of host memory for records");
+        if ((rc = pfac_records_d2h(ctx, slot, NULL, c->rec, 0, n))) return fail(w, ctx, rc, "d2h");
+    }
     if ((rc = pfac_slot_sync(ctx, slot))) return fail(w, ctx, rc, "sync");
     pthread_mutex_lock(&g_mu);
     c->done = 1;
@@ -303,7 +317,10 @@ int main(int argc, char *argv[]) {
         pthread_mutex_unlock(&g_mu);
         if (!ok) break;
         double e0 = now_ms();
-        if (pfac_emit_records_mt(fpout, chunks[k].rec, chunks[k].n_rec, chunks[k].base, tab->idmap, emit_threads) < 0) {
+        const int64_t wrote = chunks[k].words
+            ? pfac_emit_packed(fpout, chunks[k].words, chunks[k].tix, chunks[k].n_tiles, chunks[k].base, tab->idmap, emit_threads)
+            : pfac_emit_records_mt(fpout, chunks[k].rec, chunks[k].n_rec, chunks[k].base, tab->idmap, emit_threads);
+        if (wrote < 0) {
             fprintf(stderr, "write failed\n");
             emit_failed = 1;
             pthread_mutex_lock(&g_mu); g_failed = 1; pthread_cond_broadcast(&g_cv); pthread_mutex_unlock(&g_mu);
@@ -311,8 +328,8 @@ int main(int argc, char *argv[]) {
         }
         emit_ms += now_ms() - e0;
         total += chunks[k].n_rec;
-        free(chunks[k].rec);
-        chunks[k].rec = NULL;
+        free(chunks[k].rec); free(chunks[k].words); free(chunks[k].tix);
+        chunks[k].rec = NULL; chunks[k].words = NULL; chunks[k].tix = NULL;
         pthread_mutex_lock(&g_mu);
         g_emitted = k + 1;
         pthread_cond_broadcast(&g_cv);

@@ -246,21 +246,58 @@ int pfac_table_build_mem_part(const void *patterns, size_t n_bytes, int width, i
  * Escape-aware reader: the reference's read_pattern_ext() / fgetc_ext() (create_table_reorder.c:131-185,
  * ctdef.h:37-99; present but never called there).  Inside a pattern a backslash introduces
  *   \a \b \t \n \v \f \r   control characters      \' \" \\   the character itself
- *   \ooo   up to three octal digits (fscanf "%3o")     \xNN   up to two hex digits (fscanf "%2x")
+ *   \ooo   up to three octal digits      \xNN   up to two hex digits
  * any other "\c" is a literal backslash followed by c; only a REAL newline ends a pattern, so patterns may
- * contain '\n' bytes.  The same libc scanning calls are used on the stream, so odd inputs ("\8", "\x" with no
- * digits -> byte 0) resolve exactly as they would there.
+ * contain '\n' bytes.  The reference scans the numbers with fscanf("%3o") / fscanf("%2x") on the stream; this is
+ * an in-memory parser of the same grammar, odd inputs included (scan_escape_number() below follows glibc's
+ * integer conversion step by step: "\8" is byte 0 followed by '8', "\x" without digits is byte 0, white space --
+ * even a newline -- between "\x" and its digits is skipped, a sign or a "0x" prefix counts against the width).
+ * tests/test_table.py pins it against the reference's own reader on hand-picked and on fuzzed pattern files.
  */
 #define PFAC_EOL 0x10A
-static int fgetc_escaped(FILE *fp) {
-    int c0 = fgetc(fp);
+typedef struct { const unsigned char *p, *end; } mem_cursor;
+static int cur_getc(mem_cursor *c) { return c->p < c->end ? *c->p++ : EOF; }
+static void cur_ungetc(mem_cursor *c, int ch) { if (ch != EOF) c->p--; }
+
+/* fscanf(fp, "%<width>o" or "%<width>x", value): *value is written only when a number was matched */
+static void scan_escape_number(mem_cursor *c, unsigned base, int width, unsigned *value) {
+    int ch;
+    do ch = cur_getc(c); while (ch == ' ' || (ch >= '\t' && ch <= '\r'));   /* leading white space, not counted */
+    if (ch == EOF) return;                                                    /* input failure */
+    int negative = 0, have_sign = 0, n_digits = 0;
+    unsigned acc = 0;
+    if (ch == '-' || ch == '+') { negative = ch == '-'; have_sign = 1; width--; ch = cur_getc(c); }
+    if (width != 0 && ch == '0') {
+        width--; n_digits = 1;
+        ch = cur_getc(c);
+        if (width != 0 && (ch == 'x' || ch == 'X') && base == 16) { width--; ch = cur_getc(c); }
+    }
+    while (ch != EOF && width != 0) {
+        unsigned d;
+        if (ch >= '0' && ch <= '9') d = (unsigned)(ch - '0');
+        else if (ch >= 'a' && ch <= 'f') d = (unsigned)(ch - 'a') + 10;
+        else if (ch >= 'A' && ch <= 'F') d = (unsigned)(ch - 'A') + 10;
+        else break;
+        if (d >= base) break;
+        acc = acc * base + d;
+        n_digits++; width--;
+        ch = cur_getc(c);
+    }
+    cur_ungetc(c, ch);                       /* the character after the number (a lone sign stays consumed) */
+    (void)have_sign;
+    if (n_digits == 0) return;               /* matching failure */
+    *value = negative ? 0u - acc : acc;
+}
+
+static int getc_escaped(mem_cursor *c) {
+    const int c0 = cur_getc(c);
     if (c0 == '\\') {
-        int c1 = fgetc(fp);
+        const int c1 = cur_getc(c);
         unsigned value = 0;
-        if (feof(fp)) return c0;
+        if (c1 == EOF) return c0;
         if (c1 >= '0' && c1 <= '9') {
-            ungetc(c1, fp);
-            if (fscanf(fp, "%3o", &value) != 1) value = 0;
+            cur_ungetc(c, c1);
+            scan_escape_number(c, 8, 3, &value);
             return (int)(char)value;
         }
         switch (c1) {
@@ -273,10 +310,10 @@ static int fgetc_escaped(FILE *fp) {
             case 'r': return '\r';
             case '\'': case '"': case '\\': return c1;
             case 'x':
-                if (fscanf(fp, "%2x", &value) != 1) value = 0;
+                scan_escape_number(c, 16, 2, &value);
                 return (int)(char)value;
             default:
-                ungetc(c1, fp);
+                cur_ungetc(c, c1);
                 return c0;
         }
     }
@@ -284,14 +321,8 @@ static int fgetc_escaped(FILE *fp) {
     return c0;
 }
 
-int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len) {
-    if (!pattern_file || !out) return PFAC_E_ARG;
-    *out = NULL;
-    if (!is_pow2(width) || width > PFAC_COL_MAX) {
-        set_err(err, err_len, "PHF width %ld must be a power of two <= 4096", width); return PFAC_E_ARG;
-    }
-    FILE *f = fopen(pattern_file, "rb");
-    if (!f) { if (err && err_len) snprintf(err, err_len, "cannot open pattern file %s", pattern_file); return PFAC_E_IO; }
+static int build_escaped_mem(const unsigned char *img, size_t n_bytes, int width, pfac_table **out, char *err, size_t err_len) {
+    mem_cursor cur = {img, img + n_bytes};
     size_t cap = 1024, n = 0, arena_cap = 1 << 16, arena_len = 0, total = 0;
     pat_t *pats = (pat_t *)malloc(cap * sizeof(pat_t));
     size_t *offs = (size_t *)malloc(cap * sizeof(size_t));
@@ -302,9 +333,10 @@ int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_tabl
     while (pats && offs && arena) {
         int len = 0, ch, eof_inside = 0;
         for (;;) {
-            ch = fgetc_escaped(f);
+            const int at_end = cur.p >= cur.end;
+            ch = getc_escaped(&cur);
             if (ch == PFAC_EOL) break;
-            if (ch == EOF && feof(f)) { eof_inside = 1; break; }
+            if (ch == EOF && at_end) { eof_inside = 1; break; }
             str[len++] = (unsigned char)ch;
             if (len > PFAC_MAX_PATTERN_LEN) break;
         }
@@ -330,17 +362,39 @@ int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_tabl
         total += (size_t)len;
         if (len > max_len) max_len = len;
         n++;
-        ch = fgetc(f);                                  /* end of file after a newline? (ctr.c:174-180) */
-        if (feof(f)) break;
-        ungetc(ch, f);
+        if (cur.p >= cur.end) break;                    /* end of file after a newline (ctr.c:174-180) */
     }
-    fclose(f);
     if (!pats || !offs || !arena) { free(pats); free(offs); free(arena); set_err(err, err_len, "out of memory (%ld patterns)", (long)n); return PFAC_E_NOMEM; }
     if (rc) { free(pats); free(offs); free(arena); return rc; }
     for (size_t i = 0; i < n; i++) pats[i].pat = arena + offs[i];
     free(offs);
     rc = build_from_patterns(pats, n, total, max_len, width, 0, 1, out, err, err_len);
     free(arena);
+    return rc;
+}
+
+int pfac_table_build_file_escaped(const char *pattern_file, int width, pfac_table **out, char *err, size_t err_len) {
+    if (!pattern_file || !out) return PFAC_E_ARG;
+    *out = NULL;
+    if (!is_pow2(width) || width > PFAC_COL_MAX) {
+        set_err(err, err_len, "PHF width %ld must be a power of two <= 4096", width); return PFAC_E_ARG;
+    }
+    FILE *f = fopen(pattern_file, "rb");
+    if (!f) { if (err && err_len) snprintf(err, err_len, "cannot open pattern file %s", pattern_file); return PFAC_E_IO; }
+    size_t cap = 1 << 16, n = 0;
+    unsigned char *img = (unsigned char *)malloc(cap);
+    while (img) {
+        n += fread(img + n, 1, cap - n, f);
+        if (n < cap) break;
+        cap *= 2;
+        img = (unsigned char *)realloc(img, cap);
+    }
+    const int io_error = ferror(f);
+    fclose(f);
+    if (!img) { set_err(err, err_len, "out of memory (%ld bytes of pattern file)", (long)n); return PFAC_E_NOMEM; }
+    if (io_error) { free(img); if (err && err_len) snprintf(err, err_len, "cannot read pattern file %s", pattern_file); return PFAC_E_IO; }
+    const int rc = build_escaped_mem(img, n, width, out, err, err_len);
+    free(img);
     return rc;
 }
 

@@ -178,3 +178,27 @@ def emit_records(path_or_file, records: np.ndarray, idmap, base: int = 0, append
     if n < 0:
         raise PfacError(int(n), "pfac_emit_records")
     return int(n)
+
+
+def emit_packed(path, words: np.ndarray, tile_index: np.ndarray, idmap, base: int = 0, threads: int = 1) -> int:
+    """The same text straight from the compact device form (``GpuMatcher.packed_to_host``): record heap + ordered tile
+    index (include/pfac.h).  Returns bytes written."""
+    L = host_lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    tix = np.ascontiguousarray(tile_index, dtype=np.uint64)
+    idmap = None if idmap is None else np.ascontiguousarray(idmap, dtype=np.int32)
+    f = libc.fopen(os.fsencode(path), b"wb")
+    if not f:
+        raise PfacError(-2, f"cannot open {path}")
+    try:
+        n = L.pfac_emit_packed(f, words.ctypes.data, tix.ctypes.data, tix.size, int(base),
+                               None if idmap is None else idmap.ctypes.data, int(threads))
+    finally:
+        libc.fclose(f)
+    if n < 0:
+        raise PfacError(int(n), "pfac_emit_packed")
+    return int(n)

@@ -21,6 +21,7 @@ def pytest_configure(config):
     # product libs + oracle must exist (both are built in-tree by __graft_entry__.build())
     need = [os.path.join(REPO, "phfpfac_amd", "lib", "libpfac_host.so"),
             os.path.join(REPO, "phfpfac_amd", "lib", "libpfac_hip.so"),
+            os.path.join(REPO, "phfpfac_amd", "lib", "libpfac_seam.so"),
             os.path.join(REPO, "oracle", "liboracle.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=REPO)

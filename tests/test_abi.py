@@ -52,3 +52,16 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
                 txt = open(os.path.join(root, f), errors="replace").read()
                 assert "liboracle" not in txt and "pfac_oracle" not in txt and "import orc" not in txt, os.path.join(root, f)
+
+
+def test_reference_seam_library_exports_the_reference_names():
+    """libpfac_seam.so defines the three functions main.cc:35-37 declares, with C++ linkage and the reference's
+    parameter lists (thread_data by value; the cudaStream_t is a void*)."""
+    lib = os.path.join(_ffi.LIB_DIR, "libpfac_seam.so")
+    blob = open(lib, "rb").read()
+    for mangled in (b"_Z17GPU_Malloc_Memory11thread_dataPPhPPiS3_PPjS3_S3_", b"_Z14GPU_TraceTable11thread_dataPvPhPiS2_PjS2_S2_",
+                    b"_Z15GPU_Free_memoryPPhPPiS2_PPjS2_S2_"):
+        assert mangled in blob
+    hdr = open(os.path.join(REPO, "include", "pfac_seam.h")).read()
+    for name in ("GPU_Malloc_Memory", "GPU_TraceTable", "GPU_Free_memory", "struct thread_data"):
+        assert name in hdr

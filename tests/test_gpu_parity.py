@@ -559,3 +559,215 @@ def test_deeply_nested_patterns_every_offset_matches_hundreds(tmp_path):
     pos, ids = oracle_pairs(str(pf), data)
     assert rec.size == pos.size and rec.size > 10_000_000
     assert_same(table, rec, pos, ids)
+
+
+# ---------------------------------------------------------------------------
+# round 2: the rows the round-1 review found untested behind the HIP scan
+
+def test_reference_seam_by_its_own_names(resolve, tmp_path):
+    """GPU_Malloc_Memory / GPU_TraceTable / GPU_Free_memory with the reference's parameter lists
+    (main.cc:35-37), compiled (libpfac_seam.so) and driven by a program with the shape of the reference's main():
+    4 x streamnum pattern chunks, thread_data per chunk, dense input_size x max_pat_len results, the position-major
+    merge and the fprintf loop of main.cc:304-350.  Its GPU_match_result.txt must be the golden file."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "phfpfac_amd", "bin", "gphf_seam")
+    for case, streams in (("exp_x_1M_s1_w256", 1), ("all_x_1M_s2_w256", 2), ("xaa_x_1M_s1_w256", 1)):
+        c = FP["cases"][case]
+        subprocess.check_call([exe, resolve(c["pattern"]), str(streams), str(c["width"]), resolve(c["input"])], cwd=tmp_path)
+        blob = (tmp_path / "GPU_match_result.txt").read_bytes()
+        assert len(blob) == c["bytes"] and hashlib.md5(blob).hexdigest() == c["md5"], case
+    lib = os.path.join(os.path.dirname(HERE), "phfpfac_amd", "lib", "libpfac_seam.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    for name in ("GPU_Malloc_Memory", "GPU_TraceTable", "GPU_Free_memory"):
+        assert name in syms
+
+
+def test_gphf_parallel_emitter_behind_the_scan(resolve, tmp_path):
+    """SURVEY 8(f)1 behind the HIP scan: ONE 64 MiB chunk that yields ~5 M records goes through the multi-threaded
+    emitter (PFAC_EMIT_THREADS=8, well above its 524 288-record threshold), printing straight from the compact
+    device form (record heap + tile index); the file must equal the oracle's text byte for byte."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "phfpfac_amd", "bin", "gphf")
+    para = open(resolve("paragraph402"), "rb").read()
+    n = (64 << 20) - 4097
+    big = tmp_path / "big64.txt"
+    big.write_bytes(tiled_bytes(n + 1, para).tobytes())        # + the byte the CLI drops (main.cc:138)
+    env = dict(os.environ, PFAC_EMIT_THREADS="8")
+    out = subprocess.run([exe, resolve("experimentpattern"), "1", "256", str(big)], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, check=True).stdout
+    matches = int([l for l in out.splitlines() if l.startswith("4.Time for  emit")][0].split()[4])
+    assert matches > 4 * (1 << 17)
+    o = Oracle(resolve("experimentpattern"), 1, 1)
+    exp = tmp_path / "expected.txt"
+    cnt, _ = o.emit(tiled_bytes(n, para), str(exp), spec=True)
+    o.close()
+    assert cnt == matches
+    got = hashlib.md5((tmp_path / "GPU_match_result.txt").read_bytes()).hexdigest()
+    assert got == hashlib.md5(exp.read_bytes()).hexdigest()
+
+
+def test_compact_form_to_text(resolve, tmp_path):
+    """The compact device form itself (heap words + tile index, pfac_records_d2h_packed) printed by pfac_emit_packed
+    == the sorted 8-byte records printed by pfac_emit_records, on a golden case; the heap holds every record once."""
+    from phfpfac_amd import emit_packed
+    c = FP["cases"]["all_x_1M_s1_w256"]
+    table = PfacTable.from_file(resolve(c["pattern"]), c["width"])
+    data = np.frombuffer(open(resolve(c["input"]), "rb").read()[:-1], dtype=np.uint8)
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        rec = g.scan_bytes(data)
+        packed, n_tiles, used = g.scan_format(0)
+        words, tix = g.packed_to_host(0)
+    assert packed and n_tiles == -(-data.size // 4096) and words.size == used >= rec.size
+    cnt = (tix >> np.uint64(40)).astype(np.int64)
+    first = (tix & np.uint64((1 << 40) - 1)).astype(np.int64)
+    assert int(cnt.sum()) == rec.size == c["lines"]
+    spans = sorted((int(f), int(f + n)) for f, n in zip(first, cnt) if n)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= used     # tiles never overlap in the heap
+    out = tmp_path / "packed.txt"
+    for threads in (1, 5):
+        assert emit_packed(str(out), words, tix, table.idmap, threads=threads) == c["bytes"]
+        assert hashlib.md5(out.read_bytes()).hexdigest() == c["md5"]
+
+
+ESCAPED_PATTERNS = (b"tab\\there\n" b"nl\\nin\\\\side\n" b"hex\\x41\\xfe\\x7\n" b"oct\\101\\7\\377\\0end\n"
+                    b"odd\\8\\q\\'\\\"\n" b"plain\n" b"\\xff\\xfe\n" b"a\\nb\n" b"\\0\n")
+
+
+def test_escaped_pattern_file_scanned_on_the_gpu(tmp_path):
+    """SURVEY 8(f)4 behind the HIP scan: a pattern file with \\n \\xNN \\ooo escapes (patterns that contain newline and
+    NUL bytes) built with pfac_table_build_file_escaped, scanned on the GPU, records == the oracle's escape-aware
+    pipeline on the same bytes (create_table_reorder.c:131-185)."""
+    pf = tmp_path / "esc"
+    pf.write_bytes(ESCAPED_PATTERNS)
+    table = PfacTable.from_file(str(pf), 256, escapes=True)
+    assert table.n_patterns == 9
+    rng = np.random.default_rng(5)
+    raw = [b"tab\there", b"nl\nin\\side", b"hexA\xfe\x07", b"octA\x07\xff\x00end", b"odd\x008\\q'\"", b"plain", b"\xff\xfe",
+           b"a\nb", b"\x00"]
+    pieces = []
+    for _ in range(30000):
+        k = int(rng.integers(0, len(raw) + 3))
+        pieces.append(raw[k] if k < len(raw) else bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)))
+    data = np.frombuffer(b"".join(pieces), dtype=np.uint8)
+    rec = gpu_records(table, data)
+    o = Oracle(str(pf), 1, 1, escapes=True)
+    pos, ids = o.scan_spec(data)
+    o.close()
+    assert pos.size > 30000 and set(np.unique(ids)) == set(range(1, 10))
+    assert_same(table, rec, pos, ids)
+
+
+def test_config3_four_slots_streamed_at_size(resolve):
+    """BASELINE config 3 at size: 4 GiB of text in four 1 GiB chunks through FOUR pipeline slots on their own HIP
+    streams -- H2D from host memory (hipMemcpyAsync), scan, count -- all four in flight together.  Count from the
+    input's period; per-chunk checksums (linearity, base = chunk offset) against the same chunks scanned one at a
+    time out of a device-filled buffer."""
+    import torch
+    para = open(resolve("paragraph402"), "rb").read()
+    pat = resolve("experimentpattern")
+    table = PfacTable.from_file(pat, 256)
+    chunk, K = 1 << 30, 4
+    N = chunk * K
+    host = tiled_bytes(chunk + 402 + 64, para)                  # chunk k = host[phase_k : phase_k + n_avail]
+    win = tiled_bytes(402 * 8, para)
+    pos, _ = oracle_pairs(pat, win)
+    per_period = int(((pos >= 402) & (pos < 804)).sum())
+    full, tail = divmod(N, 402)
+    lpos, _ = oracle_pairs(pat, tiled_bytes(tail, para))
+    expect_total = per_period * full + lpos.size
+    with GpuMatcher(0, K) as g:
+        g.load_table(table)
+        assert len({g.stream_handle(s) for s in range(K)}) == K      # four distinct streams
+        counts, sums = [], []
+        for s in range(K):
+            g.reserve(s, chunk + table.halo, chunk // 8)
+        for s in range(K):                                      # everything enqueued before anything is waited for
+            lo = s * chunk
+            n_avail = min(N, lo + chunk + table.halo) - lo
+            ph = lo % 402
+            g.h2d(host[ph: ph + n_avail], slot=s)
+            g.scan_async(chunk, n_avail, slot=s)
+        for s in range(K):
+            n, over = g.scan_finish(s)
+            assert not over
+            counts.append(n)
+            sums.append(g.checksum(n, base=s * chunk, slot=s))
+        assert sum(counts) == expect_total
+        # the same chunks, one at a time, from a buffer filled on the device
+        buf = torch.empty(chunk + 4096, dtype=torch.uint8, device="cuda:0")
+        for s in range(K):
+            lo = s * chunk
+            n_avail = min(N, lo + chunk + table.halo) - lo
+            g.fill_tiled(buf, n_avail, para, phase=lo % 402)
+            n = g.scan_resident(chunk, n_avail, d_input=buf)
+            assert n == counts[s] and g.checksum(n, base=lo) == sums[s]
+
+
+def test_protocol_timeout_is_reported_not_hidden(resolve, monkeypatch):
+    """The error channel: with PFAC_FAULT=1 workgroup 1 never publishes the record bases of its second round, so its
+    waves run into the (shortened) bounded wait; the flags travel through device memory to the host and
+    pfac_scan_finish must return PFAC_E_INTERNAL -- and the next scan of the same context must be exact again."""
+    import torch
+    from phfpfac_amd._ffi import PFAC_E_INTERNAL
+    para = open(resolve("paragraph402"), "rb").read()
+    pat = resolve("experimentpattern")
+    N = 64 << 20
+    buf = torch.empty(N + 4096, dtype=torch.uint8, device="cuda:0")
+    pos, _ = oracle_pairs(pat, tiled_bytes(1 << 20, para))
+    monkeypatch.setenv("PFAC_FAULT", "1")
+    monkeypatch.setenv("PFAC_SPIN_MAX", "20000")
+    with GpuMatcher(0, 1) as g:
+        g.load_table(PfacTable.from_file(pat, 256))            # knobs are read when a table is installed
+        g.fill_tiled(buf, N, para)
+        g.reserve(0, 0, N // 8)
+        g.scan_async(N, N, d_input=buf)
+        with pytest.raises(PfacError) as e:
+            g.scan_finish(0)
+        assert e.value.status == PFAC_E_INTERNAL and "timeout" in str(e.value)
+        monkeypatch.delenv("PFAC_FAULT")
+        monkeypatch.delenv("PFAC_SPIN_MAX")
+        g.load_table(PfacTable.from_file(pat, 256))
+        assert g.scan_resident(1 << 20, 1 << 20, d_input=buf) == pos.size
+
+
+def test_two_slots_on_their_own_streams_large_scans(resolve):
+    """Two persistent grids at once: two slots on DISTINCT non-blocking streams, 256 MiB each, enqueued back to back
+    so their workgroups compete for the CUs (what gphf does with streamnum >= 2).  Counts must be exact every time."""
+    import torch
+    para = open(resolve("paragraph402"), "rb").read()
+    pat = resolve("experimentpattern")
+    n = 256 << 20
+    pos, _ = oracle_pairs(pat, tiled_bytes(402 * 8, para))
+    per_period = int(((pos >= 402) & (pos < 804)).sum())
+    with GpuMatcher(0, 2) as g:
+        g.load_table(PfacTable.from_file(pat, 256))
+        assert g.stream_handle(0) != g.stream_handle(1)
+        bufs = [torch.empty(n + 4096, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+        for s in range(2):
+            g.fill_tiled(bufs[s], n, para, phase=100 * s)
+            g.reserve(s, 0, n // 8)
+        ref = [g.scan_resident(n, n, d_input=bufs[s], slot=s) for s in range(2)]
+        assert all(abs(r - per_period * n / 402) < per_period + 8 for r in ref)
+        for _ in range(6):
+            for s in range(2):
+                g.scan_async(n, n, d_input=bufs[s], slot=s)
+            assert [g.scan_finish(s)[0] for s in range(2)] == ref
+
+
+def test_snort_scale_table_on_random_input(resolve):
+    """BASELINE config 5's own input kind: the 75 840-pattern set (tables through L2, level-2 filter in its lookup
+    form with the second-byte pre-filter) on splitmix64 random bytes, records == oracle; and with the filters off."""
+    table = PfacTable.from_file(resolve("bytefile/1000000byte"), 256)
+    n = 3 << 20
+    data = splitmix64_bytes(n, 0x5048465046414331)
+    pos, ids = oracle_pairs(resolve("bytefile/1000000byte"), data)
+    assert pos.size > 50000
+    rec = gpu_records(table, data)
+    assert_same(table, rec, pos, ids)
+    for knob in ("PFAC_NO_SECF", "PFAC_L2F"):
+        os.environ[knob] = "1" if knob == "PFAC_NO_SECF" else "0"
+        try:
+            assert_same(table, gpu_records(table, data), pos, ids)
+        finally:
+            del os.environ[knob]

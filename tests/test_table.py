@@ -193,3 +193,86 @@ def test_escape_aware_reader(tmp_path):
             assert (np.ctypeslib.as_array(ref.orc_trie_row(b, 0, st), (256,)) == dense[st]).all()
         assert (np.ctypeslib.as_array(ref.orc_idmap(b, 0), (6,)) == o.idmap()).all()
     o.close()
+
+
+def test_escape_reader_fuzz_against_the_reference_reader(tmp_path):
+    """Differential fuzz of the in-memory escape parser (pfac_table.c: getc_escaped / scan_escape_number) against the
+    reference's own read_pattern_ext + fgetc_ext, which scan \\ooo and \\xNN with fscanf on the stream (compiled from
+    the reference sources into oracle/_ref): pattern files full of backslashes, digits beyond 7, 'x', signs, "0x"
+    prefixes and white space after "\\x" -- the inputs on which a hand-written parser and libc's scanf disagree."""
+    import ctypes as C
+    import os
+    ref_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libpfacref.so")
+    if not os.path.exists(ref_lib):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    ref = C.CDLL(ref_lib)
+    ref.ref_build_single_ext.restype = C.c_void_p; ref.ref_build_single_ext.argtypes = [C.c_char_p]
+    ref.orc_state_num.argtypes = [C.c_void_p, C.c_int]
+    ref.orc_num_patterns.argtypes = [C.c_void_p]
+    ref.orc_trie_row.restype = C.POINTER(C.c_int); ref.orc_trie_row.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    ref.orc_idmap.restype = C.POINTER(C.c_int); ref.orc_idmap.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(20261004)
+    alphabet = [b"\\", b"\\", b"\\", b"x", b"x", b"0", b"1", b"7", b"8", b"9", b"a", b"f", b"g", b"A", b"F", b"q", b"n", b"t",
+                b" ", b"\t", b"\r", b"+", b"-", b"X", b"'", b"\"", b"3", b"5", b"z", b"\xfe", b"\x00"]
+    for trial in range(60):
+        lines = []
+        for _ in range(int(rng.integers(1, 12))):
+            k = int(rng.integers(1, 14))
+            line = b"".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), k))
+            lines.append(line + b"\n")
+        if trial % 5 == 0:
+            lines.insert(0, b"\\x\n41\\x \t7q\\0x41\\x0x41\\+7\\x-f\\x+\n")     # white space / sign / prefix after an escape
+        img = b"".join(lines)
+        if img.endswith(b"\\\n") or img.endswith(b"\\x\n"):            # an escape that swallows the final newline: the
+            img += b"end\n"                                           # reference then reads past EOF and exits
+        pf = tmp_path / f"fz{trial}"
+        pf.write_bytes(img)
+        b = ref.ref_build_single_ext(os.fsencode(str(pf)))
+        n_pat = ref.orc_num_patterns(b)
+        S = ref.orc_state_num(b, 0)
+        t = PfacTable.from_file(str(pf), 256, escapes=True)
+        assert t.n_patterns == n_pat and t.state_num == S, (trial, img)
+        dense = np.stack([np.ctypeslib.as_array(ref.orc_trie_row(b, 0, st), (256,)) for st in range(S)])
+        assert (lookup_all(t) == dense).all(), (trial, img)
+        assert (np.ctypeslib.as_array(ref.orc_idmap(b, 0), (n_pat,)) == t.idmap).all(), (trial, img)
+
+
+def test_emit_from_record_heap_and_tile_index(tmp_path):
+    """pfac_emit_packed prints the compact device form -- 32-bit words scattered over a heap with gaps, ordered only by
+    the tile index -- to the same bytes as the 8-byte-record emitters, serial and multi-threaded."""
+    from phfpfac_amd import RECORD_DTYPE, emit_packed, emit_records
+    rng = np.random.default_rng(11)
+    n_tiles = 1600
+    counts = rng.integers(0, 1200, n_tiles)
+    counts[rng.random(n_tiles) < 0.3] = 0                    # empty tiles
+    order = rng.permutation(n_tiles)                         # where each tile's run sits in the heap: any order, with gaps
+    first = np.zeros(n_tiles, dtype=np.uint64)
+    at = 0
+    for t in order:
+        at += int(rng.integers(0, 9))
+        first[t] = at
+        at += int(counts[t])
+    words = rng.integers(0, 1 << 32, at + 5, dtype=np.uint64).astype(np.uint32)     # garbage in the gaps
+    idmap = rng.integers(1, 3_000_000, 1 << 20).astype(np.int32)
+    rec = np.empty(int(counts.sum()), dtype=RECORD_DTYPE)
+    k = 0
+    for t in range(n_tiles):
+        c = int(counts[t])
+        pos = np.sort(rng.integers(0, 4096, c)).astype(np.uint32)
+        st = rng.integers(0, 1 << 20, c).astype(np.uint32)
+        words[int(first[t]): int(first[t]) + c] = pos | (st << np.uint32(12))
+        rec["pos"][k: k + c] = pos + np.uint32(t * 4096)
+        rec["state"][k: k + c] = st
+        k += c
+    tix = first | (counts.astype(np.uint64) << np.uint64(40))
+    assert rec.size > 4 * (1 << 17)                          # enough for the parallel emitter (it falls back to serial below that)
+    a, b, c_ = tmp_path / "a.txt", tmp_path / "b.txt", tmp_path / "c.txt"
+    for base in (0, 5 << 32):
+        na = emit_records(str(a), rec, idmap, base=base)
+        nb = emit_packed(str(b), words, tix, idmap, base=base)
+        nc = emit_packed(str(c_), words, tix, idmap, base=base, threads=6)
+        assert na == nb == nc
+        assert a.read_bytes() == b.read_bytes() == c_.read_bytes()
+    # no tiles at all / only empty tiles
+    assert emit_packed(str(b), np.zeros(1, np.uint32), np.zeros(0, np.uint64), idmap) == 0
+    assert emit_packed(str(b), np.zeros(1, np.uint32), np.zeros(9, np.uint64), idmap) == 0
