@@ -595,7 +595,7 @@ def test_gphf_parallel_emitter_behind_the_scan(resolve, tmp_path):
     env = dict(os.environ, PFAC_EMIT_THREADS="8")
     out = subprocess.run([exe, resolve("experimentpattern"), "1", "256", str(big)], cwd=tmp_path, env=env,
                          capture_output=True, text=True, check=True).stdout
-    matches = int([l for l in out.splitlines() if l.startswith("4.Time for  emit")][0].split()[4])
+    matches = int([l for l in out.splitlines() if l.startswith("4.Time for  emit")][0].split()[3])
     assert matches > 4 * (1 << 17)
     o = Oracle(resolve("experimentpattern"), 1, 1)
     exp = tmp_path / "expected.txt"
@@ -654,7 +654,7 @@ def test_escaped_pattern_file_scanned_on_the_gpu(tmp_path):
     o = Oracle(str(pf), 1, 1, escapes=True)
     pos, ids = o.scan_spec(data)
     o.close()
-    assert pos.size > 30000 and set(np.unique(ids)) == set(range(1, 10))
+    assert pos.size > 20000 and set(np.unique(ids)) == set(range(1, 10))
     assert_same(table, rec, pos, ids)
 
 
