@@ -1535,6 +1535,26 @@ int fail(pfac_ctx *ctx, int code, const std::string &msg) {
             return fail(ctx, PFAC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+// Every entry point works on its context's device and leaves the calling thread's current device as it found it
+// (a caller that drives several GPUs from one thread -- torch does -- must not have it changed under its feet).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define USE_DEVICE(ctx)                                                                                    \
+    DeviceGuard device_guard_((ctx)->device);                                                              \
+    if (device_guard_.err != hipSuccess)                                                                   \
+        return fail(ctx, PFAC_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_guard_.err))
+
 int check_slot(pfac_ctx *ctx, int slot) {
     if (!ctx) return fail(nullptr, PFAC_E_ARG, "null context");
     if (slot < 0 || slot >= (int)ctx->slots.size()) return fail(ctx, PFAC_E_ARG, "bad slot index");
@@ -1791,7 +1811,7 @@ int pfac_ctx_create(int device, int n_streams, pfac_ctx **out) {
     if (device < 0 || device >= n) return fail(nullptr, PFAC_E_NO_DEVICE, "device index out of range");
     pfac_ctx *ctx = new pfac_ctx();
     ctx->device = device;
-    HIP_TRY(ctx, hipSetDevice(device));
+    USE_DEVICE(ctx);
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
     ctx->n_cu = prop.multiProcessorCount;
@@ -1812,7 +1832,7 @@ int pfac_ctx_create(int device, int n_streams, pfac_ctx **out) {
 
 void pfac_ctx_destroy(pfac_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard device_guard_(ctx->device);
     for (auto &s : ctx->slots) {
         if (s.own_stream) (void)hipStreamSynchronize(s.own_stream);
         if (s.d_input) (void)hipFree(s.d_input);
@@ -1838,7 +1858,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
 int pfac_table_upload(pfac_ctx *ctx, const int32_t *blob, size_t n_words) {
     if (!ctx || !blob || n_words < PFAC_BLOB_HEADER_WORDS) return fail(ctx, PFAC_E_ARG, "bad argument to pfac_table_upload");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     int *d_blob = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d_blob, n_words * 4));
     hipError_t e = hipMemcpy(d_blob, blob, n_words * 4, hipMemcpyHostToDevice);   // master_kernel.cu:365-383
@@ -1851,7 +1871,7 @@ int pfac_table_upload(pfac_ctx *ctx, const int32_t *blob, size_t n_words) {
 int pfac_table_upload_device(pfac_ctx *ctx, const void *d_blob, size_t n_words, void *stream_handle) {
     if (!ctx || !d_blob || n_words < PFAC_BLOB_HEADER_WORDS) return fail(ctx, PFAC_E_ARG, "bad argument to pfac_table_upload_device");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_handle);
     int32_t hdr[PFAC_BLOB_HEADER_WORDS];
     HIP_TRY(ctx, hipMemcpyAsync(hdr, d_blob, sizeof hdr, hipMemcpyDeviceToHost, st));
@@ -1870,7 +1890,7 @@ void pfac_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int pfac_slot_reserve(pfac_ctx *ctx, int slot, uint64_t input_bytes, uint64_t record_capacity) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     Slot &s = ctx->slots[slot];
     if (input_bytes > s.input_cap) {
         if (s.d_input) { HIP_TRY(ctx, hipFree(s.d_input)); s.d_input = nullptr; s.input_cap = 0; }
@@ -1905,7 +1925,7 @@ int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, u
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     if (!host || dst_offset + n_bytes > s.input_cap) return fail(ctx, PFAC_E_ARG, "pfac_slot_h2d: range exceeds the reserved input buffer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(s.d_input + dst_offset, host, n_bytes, hipMemcpyHostToDevice, s.stream));
     return PFAC_OK;
 }
@@ -1924,7 +1944,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     if (!d_input && n_avail > s.input_cap) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: n_avail exceeds the reserved input buffer");
     if (((uintptr_t)d_records & 15) != 0) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: record buffer must be 16-byte aligned");
     if (!d_records && capacity) return fail(ctx, PFAC_E_ARG, "pfac_scan_async: no record buffer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     const uint64_t n_tiles = (n_owned + WTILE - 1) / WTILE;
     if (s.pending) HIP_TRY(ctx, hipStreamSynchronize(s.stream));   // the previous scan of this slot still owns h_ctl
     s.last_cap = capacity;
@@ -2013,7 +2033,7 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_scan_finish without a scan");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     // wait for THIS scan's end event, not for the stream: another slot may share the stream (launch pipelining), and
     // its scan -- enqueued after this one -- should keep the GPU busy while the host reads this result
     HIP_TRY(ctx, hipEventSynchronize(s.ev1));
@@ -2117,7 +2137,7 @@ int pfac_records_expand(pfac_ctx *ctx, int slot, const void *d_records, uint64_t
     const void *src = d_records ? d_records : s.d_records;
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_expand without a scan");
     if (!src || (!d_out && n) || ((uintptr_t)d_out & 7)) return fail(ctx, PFAC_E_ARG, "pfac_records_expand: bad buffer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     return expand_records(ctx, s, src, first, n, d_out);
 }
 
@@ -2129,7 +2149,7 @@ int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record
     if (!src || (!host && n)) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h: null buffer");
     if (n == 0) return PFAC_OK;
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h without a scan");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     if (n > s.wide_cap) {
         if (s.d_wide) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_wide)); s.d_wide = nullptr; s.wide_cap = 0; }
         HIP_TRY(ctx, hipMalloc((void **)&s.d_wide, n * sizeof(pfac_record)));
@@ -2150,7 +2170,7 @@ int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint
     if (!s.scanned || !s.last_packed) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h_packed: the slot's last scan did not produce packed records");
     if (!src || (!host_words && n_words) || !host_tile_index) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: null buffer");
     if (n_words > s.last_cap) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: more words than the record array holds");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     if (n_words) HIP_TRY(ctx, hipMemcpyAsync(host_words, src, n_words * 4, hipMemcpyDeviceToHost, s.stream));
     if (s.last_tiles) HIP_TRY(ctx, hipMemcpyAsync(host_tile_index, s.d_tile_index, s.last_tiles * 8, hipMemcpyDeviceToHost, s.stream));
     return PFAC_OK;
@@ -2159,7 +2179,7 @@ int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint
 int pfac_slot_sync(pfac_ctx *ctx, int slot) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->slots[slot].stream));
     return PFAC_OK;
 }
@@ -2173,7 +2193,7 @@ int pfac_records_checksum(pfac_ctx *ctx, int slot, const void *d_records, uint64
     const void *src = d_records ? d_records : s.d_records;
     if (!src && n) return fail(ctx, PFAC_E_ARG, "null record buffer");
     if (n && !s.scanned) return fail(ctx, PFAC_E_STATE, "pfac_records_checksum without a scan");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     HIP_TRY(ctx, hipMemsetAsync(s.d_sum, 0, 16, s.stream));
     if (n && s.last_tiles) {
         if (s.last_packed)
@@ -2197,7 +2217,7 @@ int pfac_fill_tiled(pfac_ctx *ctx, int slot, void *d_dst, uint64_t n, const void
     if (rc) return rc;
     if (!d_dst || !host_pattern || period == 0 || ((uintptr_t)d_dst & 15)) return fail(ctx, PFAC_E_ARG, "bad argument to pfac_fill_tiled");
     Slot &s = ctx->slots[slot];
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     unsigned char *d_pat = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d_pat, period));
     hipError_t e = hipMemcpy(d_pat, host_pattern, period, hipMemcpyHostToDevice);
@@ -2217,7 +2237,7 @@ int pfac_fill_random(pfac_ctx *ctx, int slot, void *d_dst, uint64_t n, uint64_t 
     if (rc) return rc;
     if (!d_dst || ((uintptr_t)d_dst & 7) || (n & 7)) return fail(ctx, PFAC_E_ARG, "pfac_fill_random: dst and n must be multiples of 8");
     Slot &s = ctx->slots[slot];
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    USE_DEVICE(ctx);
     if (n) {
         hipLaunchKernelGGL(pfac_fill_random_kernel, dim3(2048), dim3(256), 0, s.stream,
                            static_cast<unsigned long long *>(d_dst), (unsigned long long)(n / 8), (unsigned long long)seed);
