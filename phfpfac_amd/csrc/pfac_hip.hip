@@ -575,6 +575,9 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
         deepf[w] = (e & QDEEP) != 0;
         anydeep = anydeep || deepf[w];
     }
+#ifdef PFAC_ABL_NOWALK                         // ablation builds only: deep entries are treated as shallow (wrong records)
+    anydeep = false;
+#endif
     if (!__any(anydeep)) {
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
@@ -1102,6 +1105,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                     const unsigned s32 = (ftab[nx & 0xFFu] >> 8) & 1u;
                     cand = m1 & ((((rlo >> 16) | (rhi & 0xFFFF0000u)) >> 1) | (s32 << 31));
                 }
+#ifdef PFAC_ABL_NOCLASS                        // ablation builds only: no survivor is looked up (no records)
+                cand = 0;
+#endif
                 for (unsigned mm = cand; mm;) {
                     unsigned b[L2F_UNROLL], win[L2F_UNROLL], v[L2F_UNROLL], fin[L2F_UNROLL];
                     bool on[L2F_UNROLL];
