@@ -99,6 +99,24 @@ int pfac_table_build_mem_part(const void *patterns, size_t n_bytes, int width, i
                               char *err, size_t err_len);
 void pfac_table_free(pfac_table *t);
 
+/* Character-class patterns -- the front end the reference sketches in CreateTable/charset_table_reorder.c:45-168,
+ * 321-427 (orphaned and not compilable there): a pattern is a sequence of single (escape-aware) characters and classes
+ * "[...]" / "[^...]" with "l-r" ranges; no repetition.  The subset construction yields an acyclic DFA that is used as
+ * the PFAC table unchanged (finals first, root = num_final + 1).  A final state can stand for several patterns:
+ * outputs->ids[outputs->first[s] .. outputs->first[s+1]) lists them, ascending; table->idmap[s] is the first one.
+ * num_final counts FINAL STATES here, n_patterns the lines of the file.  Parity with the reference: unpinned (its code
+ * for this cannot be built); pinned against an independent brute-force matcher (oracle/charclass_oracle.py). */
+typedef struct pfac_outputs {
+    int32_t n_states;       /* == table->num_final */
+    int32_t *first;         /* [n_states + 1] */
+    int32_t *ids;           /* pattern ids (1-based line numbers) */
+} pfac_outputs;
+int pfac_table_build_file_charclass(const char *pattern_file, int width, pfac_table **out, pfac_outputs **outputs, char *err,
+                                    size_t err_len);
+int pfac_table_build_mem_charclass(const void *patterns, size_t n_bytes, int width, pfac_table **out, pfac_outputs **outputs,
+                                   char *err, size_t err_len);
+void pfac_outputs_free(pfac_outputs *o);
+
 /* The device lookup evaluated on the host (property tests; never used on the scan path). */
 int32_t pfac_table_lookup(const pfac_table *t, int32_t state, int32_t ch);
 
@@ -143,6 +161,8 @@ typedef struct pfac_record {
 #define PFAC_TIX_COUNT(e) ((uint32_t)((uint64_t)(e) >> 40))
 /* idmap == NULL: rec.state already holds the pattern id (the output of pfac_merge_partitions). */
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap);
+/* Character-class tables: one line per (record, pattern ending in the record's final state), ascending pattern id. */
+int64_t pfac_emit_records_multi(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const pfac_outputs *outputs);
 /* Same bytes, produced by n_threads host threads (size pass, prefix sum, format + pwrite in place); the serial
  * fprintf loop is the end-to-end wall once the scan runs at TB/s.  The file must be seekable; falls back to the
  * serial emitter for small n, n_threads < 2 or pipes. */

@@ -6,7 +6,7 @@ the scan runs in a hand-written gfx950 HIP kernel (``csrc/pfac_hip.hip``) behind
 ``torch.distributed`` plumbing that shards the input byte stream across GPUs.
 """
 from ._ffi import PfacError  # noqa: F401
-from .table import RECORD_DTYPE, PfacTable, emit_packed, emit_records, merge_partitions  # noqa: F401
+from .table import RECORD_DTYPE, PfacTable, emit_packed, emit_records, emit_records_multi, merge_partitions  # noqa: F401
 from .matcher import GpuMatcher, device_count  # noqa: F401
 
-__all__ = ["PfacError", "PfacTable", "GpuMatcher", "RECORD_DTYPE", "emit_records", "emit_packed", "merge_partitions", "device_count"]
+__all__ = ["PfacError", "PfacTable", "GpuMatcher", "RECORD_DTYPE", "emit_records", "emit_packed", "emit_records_multi", "merge_partitions", "device_count"]

@@ -51,6 +51,11 @@ class CTable(C.Structure):
                [(n, C.POINTER(C.c_int32)) for n in ("s0", "r", "HT", "val", "idmap")]
 
 
+class COutputs(C.Structure):
+    """struct pfac_outputs (character-class tables: final state -> pattern ids)."""
+    _fields_ = [("n_states", C.c_int32), ("first", C.POINTER(C.c_int32)), ("ids", C.POINTER(C.c_int32))]
+
+
 class CRecord(C.Structure):
     """struct pfac_record: start offset relative to the scanned range + final state."""
     _fields_ = [("pos", C.c_uint32), ("state", C.c_uint32)]
@@ -68,7 +73,8 @@ HOST_SYMBOLS = (
     "pfac_table_build_file", "pfac_table_build_file_escaped", "pfac_table_build_mem", "pfac_table_build_file_part",
     "pfac_table_build_mem_part", "pfac_merge_partitions", "pfac_table_free", "pfac_table_lookup",
     "pfac_table_blob_words", "pfac_table_to_blob", "pfac_table_from_blob", "pfac_table_from_reference_arrays",
-    "pfac_emit_records", "pfac_emit_records_mt", "pfac_emit_packed",
+    "pfac_emit_records", "pfac_emit_records_mt", "pfac_emit_packed", "pfac_table_build_file_charclass",
+    "pfac_table_build_mem_charclass", "pfac_outputs_free", "pfac_emit_records_multi",
 )
 HIP_SYMBOLS = (
     "pfac_device_count", "pfac_ctx_create", "pfac_ctx_destroy", "pfac_last_error", "pfac_table_upload",
@@ -116,6 +122,13 @@ def host_lib() -> C.CDLL:
         L.pfac_emit_records_mt.restype = C.c_int64
         L.pfac_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.pfac_emit_packed.restype = C.c_int64
+        OP = C.POINTER(COutputs)
+        L.pfac_table_build_file_charclass.argtypes = [C.c_char_p, C.c_int, C.POINTER(TP), C.POINTER(OP), C.c_char_p, C.c_size_t]
+        L.pfac_table_build_mem_charclass.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(TP), C.POINTER(OP), C.c_char_p, C.c_size_t]
+        L.pfac_outputs_free.argtypes = [OP]
+        L.pfac_outputs_free.restype = None
+        L.pfac_emit_records_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, OP]
+        L.pfac_emit_records_multi.restype = C.c_int64
         _host = L
     return _host
 

@@ -851,3 +851,280 @@ int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile
     free(pre);
     return rc;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Character-class patterns (second half): the front end the reference sketches in
+ * CreateTable/charset_table_reorder.c (orphaned there: it is #included by nothing and does not compile).  Grammar,
+ * restated from fgetc_set() / build_NFA() (:45-168): a pattern is a sequence of ELEMENTS up to a real newline; an
+ * element is one (escape-aware, fgetc_ext) character or a class "[...]" / "[^...]" whose items are characters and
+ * ranges "l-r" (items go through the escape reader too; a '-' with no character before it is a literal '-'; the
+ * first ']' -- by VALUE, so "\x5d" as well -- closes the class, also right after "l-").  No repetition operators:
+ * every pattern has a fixed length in elements, the NFA is one chain per pattern, and the subset construction
+ * (NFA2DFA, :321-427) yields an acyclic DFA whose states are "the patterns still alive after d bytes".  That DFA IS
+ * a PFAC table (no failure links), numbered as patternsToPFAC numbers a trie: final states first (0 .. F-1, in BFS
+ * order as mark_DFA_id :429-471 does), F unused, root F+1, the other states behind it.  One difference from a plain
+ * trie: a final state can stand for SEVERAL patterns ("[ab]c" and "ac" both end in the state reached by "ac");
+ * pfac_outputs lists them, ascending pattern id, and pfac_emit_records_multi prints one line per pattern.
+ * The scan kernel is untouched: it walks whatever lookup(state, byte) says.
+ * Parity: UNPINNED against the reference (its code for this cannot be built and it holds no fixture); pinned against
+ * the independent brute-force matcher oracle/charclass_oracle.py.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t w[4]; } cset_t;
+static inline int cset_has(const cset_t *s, int c) { return (int)((s->w[c >> 6] >> (c & 63)) & 1u); }
+static inline void cset_put(cset_t *s, int c, int on) {
+    if (on) s->w[c >> 6] |= 1ull << (c & 63); else s->w[c >> 6] &= ~(1ull << (c & 63));
+}
+
+void pfac_outputs_free(pfac_outputs *o) {
+    if (!o) return;
+    free(o->first); free(o->ids); free(o);
+}
+
+typedef struct {
+    int32_t first, count, depth;    /* members[first .. first+count): ascending pattern indices */
+    int32_t id;                     /* final numbering */
+} dstate_t;
+
+static uint64_t hash_members(const int32_t *m, int32_t n, int32_t depth) {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)depth;
+    for (int32_t i = 0; i < n; i++) { h ^= (uint64_t)(uint32_t)m[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+static int build_charclass_mem(const unsigned char *img, size_t n_bytes, int width, pfac_table **out, pfac_outputs **outs,
+                               char *err, size_t err_len) {
+    /* ---- parse: elems[] arena, pattern p = elems[poff[p] .. poff[p] + plen[p]) ---- */
+    mem_cursor cur = {img, img + n_bytes};
+    size_t ecap = 1024, n_elem = 0, pcap = 256, n_pat = 0;
+    cset_t *elems = (cset_t *)malloc(ecap * sizeof(cset_t));
+    int32_t *poff = (int32_t *)malloc(pcap * sizeof(int32_t)), *plen = (int32_t *)malloc(pcap * sizeof(int32_t));
+    int rc = PFAC_OK;
+    int32_t max_len = 0;
+    while (elems && poff && plen && cur.p < cur.end && !rc) {
+        int32_t len = 0;
+        const size_t start = n_elem;
+        for (;;) {
+            const int at_end = cur.p >= cur.end;
+            int ch = getc_escaped(&cur);
+            if (ch == PFAC_EOL) break;
+            if (ch == EOF && at_end) { set_err(err, err_len, "pattern file must end with a newline (pattern %ld)", (long)n_pat + 1); rc = PFAC_E_PATTERN; break; }
+            cset_t s = {{0, 0, 0, 0}};
+            if (ch == '[') {
+                int setting = 1, have_l = 0, bad = 0;
+                unsigned char ch_l = 0;
+                ch = getc_escaped(&cur);
+                if (ch == '^') { s.w[0] = s.w[1] = s.w[2] = s.w[3] = ~0ull; setting = 0; ch = getc_escaped(&cur); }
+                while (ch != ']') {
+                    if (ch == PFAC_EOL || (ch == EOF && cur.p >= cur.end)) { bad = 1; break; }
+                    if (ch == '-' && have_l) {
+                        const int r = getc_escaped(&cur);
+                        if (r == PFAC_EOL || (r == EOF && cur.p >= cur.end)) { bad = 1; break; }
+                        for (int i = ch_l; i <= (int)(unsigned char)r; i++) cset_put(&s, i, setting);
+                    } else {
+                        ch_l = (unsigned char)ch;
+                        cset_put(&s, ch_l, setting);
+                        have_l = 1;
+                    }
+                    ch = getc_escaped(&cur);
+                }
+                if (bad) { set_err(err, err_len, "pattern %ld: character class not closed before the end of the line", (long)n_pat + 1); rc = PFAC_E_PATTERN; break; }
+            } else {
+                cset_put(&s, (unsigned char)ch, 1);
+            }
+            if (n_elem == ecap) { ecap *= 2; elems = (cset_t *)realloc(elems, ecap * sizeof(cset_t)); if (!elems) break; }
+            elems[n_elem++] = s;
+            if (++len > PFAC_MAX_PATTERN_LEN) { set_err(err, err_len, "Pattern %ld length over 1024.", (long)n_pat + 1); rc = PFAC_E_PATTERN; break; }
+        }
+        if (rc || !elems) break;
+        if (len == 0) { set_err(err, err_len, "pattern %ld is empty", (long)n_pat + 1); rc = PFAC_E_PATTERN; break; }
+        if (n_pat == pcap) {
+            pcap *= 2;
+            poff = (int32_t *)realloc(poff, pcap * sizeof(int32_t));
+            plen = (int32_t *)realloc(plen, pcap * sizeof(int32_t));
+            if (!poff || !plen) break;
+        }
+        poff[n_pat] = (int32_t)start; plen[n_pat] = len; n_pat++;
+        if (len > max_len) max_len = len;
+    }
+    if (!elems || !poff || !plen) { free(elems); free(poff); free(plen); set_err(err, err_len, "out of memory (%ld patterns)", (long)n_pat); return PFAC_E_NOMEM; }
+    if (!rc && n_pat == 0) { set_err(err, err_len, "no patterns%ld", 0); rc = PFAC_E_PATTERN; }
+    if (rc) { free(elems); free(poff); free(plen); return rc; }
+
+    /* ---- subset construction, breadth first: a state = the patterns alive after `depth` bytes ---- */
+    size_t scap = 1024, n_states = 0, mcap = 4096 + n_pat, n_mem = 0, ecap2 = 4096, n_edges = 0, hcap = 4096;
+    dstate_t *st = (dstate_t *)malloc(scap * sizeof(dstate_t));
+    int32_t *mem = (int32_t *)malloc(mcap * sizeof(int32_t));
+    edge_t *edges = (edge_t *)malloc(ecap2 * sizeof(edge_t));
+    int32_t *htab = (int32_t *)malloc(hcap * sizeof(int32_t));
+    int32_t *next = (int32_t *)malloc((n_pat ? n_pat : 1) * sizeof(int32_t));
+    int oom = !st || !mem || !edges || !htab || !next;
+    if (!oom) {
+        memset(htab, 0xFF, hcap * sizeof(int32_t));
+        for (size_t p = 0; p < n_pat; p++) mem[n_mem++] = (int32_t)p;
+        st[0].first = 0; st[0].count = (int32_t)n_pat; st[0].depth = 0; st[0].id = -1;
+        n_states = 1;
+        htab[hash_members(mem, (int32_t)n_pat, 0) & (hcap - 1)] = 0;
+    }
+    for (size_t si = 0; si < n_states && !oom && !rc; si++) {
+        const dstate_t cs = st[si];
+        for (int c = 0; c < 256 && !oom && !rc; c++) {
+            int32_t nn = 0;
+            for (int32_t k = 0; k < cs.count; k++) {
+                const int32_t p = mem[cs.first + k];
+                if (plen[p] > cs.depth && cset_has(&elems[poff[p] + cs.depth], c)) next[nn++] = p;
+            }
+            if (nn == 0) continue;
+            /* known state? (same members at the same depth) */
+            const uint64_t h = hash_members(next, nn, cs.depth + 1);
+            size_t slot = (size_t)(h & (hcap - 1));
+            int32_t found = -1;
+            while (htab[slot] >= 0) {
+                const dstate_t *o = &st[htab[slot]];
+                if (o->depth == cs.depth + 1 && o->count == nn && memcmp(mem + o->first, next, (size_t)nn * sizeof(int32_t)) == 0) { found = htab[slot]; break; }
+                slot = (slot + 1) & (hcap - 1);
+            }
+            if (found < 0) {
+                if (n_states >= (size_t)(INT32_MAX / 256) - 8) { set_err(err, err_len, "automaton too large (%ld states)", (long)n_states); rc = PFAC_E_PATTERN; break; }
+                if (n_states == scap) { scap *= 2; st = (dstate_t *)realloc(st, scap * sizeof(dstate_t)); if (!st) { oom = 1; break; } }
+                if (n_mem + (size_t)nn > mcap) { while (n_mem + (size_t)nn > mcap) mcap *= 2; mem = (int32_t *)realloc(mem, mcap * sizeof(int32_t)); if (!mem) { oom = 1; break; } }
+                memcpy(mem + n_mem, next, (size_t)nn * sizeof(int32_t));
+                st[n_states].first = (int32_t)n_mem; st[n_states].count = nn; st[n_states].depth = cs.depth + 1; st[n_states].id = -1;
+                n_mem += (size_t)nn;
+                found = (int32_t)n_states++;
+                htab[slot] = found;
+                if (n_states * 2 > hcap) {             /* rehash */
+                    hcap *= 4;
+                    free(htab);
+                    htab = (int32_t *)malloc(hcap * sizeof(int32_t));
+                    if (!htab) { oom = 1; break; }
+                    memset(htab, 0xFF, hcap * sizeof(int32_t));
+                    for (size_t q = 0; q < n_states; q++) {
+                        size_t s2 = (size_t)(hash_members(mem + st[q].first, st[q].count, st[q].depth) & (hcap - 1));
+                        while (htab[s2] >= 0) s2 = (s2 + 1) & (hcap - 1);
+                        htab[s2] = (int32_t)q;
+                    }
+                }
+            }
+            if (n_edges == ecap2) { ecap2 *= 2; edges = (edge_t *)realloc(edges, ecap2 * sizeof(edge_t)); if (!edges) { oom = 1; break; } }
+            edges[n_edges].from = (int32_t)si; edges[n_edges].ch = c; edges[n_edges].to = found; n_edges++;
+        }
+    }
+    free(next); free(htab);
+    pfac_table *t = NULL;
+    pfac_outputs *o = NULL;
+    if (!oom && !rc) {
+        /* ---- numbering: finals 0 .. F-1 in BFS (= creation) order, F unused, root F+1, the rest behind ---- */
+        int32_t F = 0, n_out = 0;
+        for (size_t q = 1; q < n_states; q++) {
+            int fin = 0;
+            for (int32_t k = 0; k < st[q].count; k++) if (plen[mem[st[q].first + k]] == st[q].depth) { fin = 1; n_out++; }
+            if (fin) st[q].id = F++;
+        }
+        int32_t nf = F + 2;
+        st[0].id = F + 1;
+        for (size_t q = 1; q < n_states; q++) if (st[q].id < 0) st[q].id = nf++;
+        t = (pfac_table *)calloc(1, sizeof *t);
+        o = (pfac_outputs *)calloc(1, sizeof *o);
+        if (t && o) {
+            t->width = width;
+            for (t->width_bit = 0; (width >> t->width_bit) != 1; t->width_bit++) ;
+            t->n_patterns = (int32_t)n_pat;
+            t->num_final = F;
+            t->state_num = nf;
+            t->max_pat_len = max_len;
+            t->idmap = (int32_t *)malloc((F ? (size_t)F : 1) * sizeof(int32_t));
+            t->s0 = (int32_t *)malloc(256 * sizeof(int32_t));
+            o->n_states = F;
+            o->first = (int32_t *)malloc(((size_t)F + 1) * sizeof(int32_t));
+            o->ids = (int32_t *)malloc((n_out ? (size_t)n_out : 1) * sizeof(int32_t));
+        }
+        if (!t || !o || !t->idmap || !t->s0 || !o->first || !o->ids) oom = 1;
+        else {
+            /* outputs per final state: the patterns that END there, ascending id (members are ascending) */
+            int32_t at = 0;
+            for (size_t q = 1; q < n_states; q++) {            /* finals were numbered in this order */
+                if (st[q].id >= F) continue;
+                o->first[st[q].id] = at;
+                for (int32_t k = 0; k < st[q].count; k++) {
+                    const int32_t p = mem[st[q].first + k];
+                    if (plen[p] == st[q].depth) o->ids[at++] = p + 1;          /* pattern id = 1-based line number */
+                }
+                t->idmap[st[q].id] = o->ids[o->first[st[q].id]];
+            }
+            o->first[F] = at;
+            memset(t->s0, 0xFF, 256 * sizeof(int32_t));
+            for (size_t e = 0; e < n_edges; e++) { edges[e].from = st[edges[e].from].id; edges[e].to = st[edges[e].to].id; }
+            qsort(edges, n_edges, sizeof(edge_t), edge_key_cmp);
+            for (size_t e = 0; e < n_edges; e++) if (edges[e].from == F + 1) t->s0[edges[e].ch] = edges[e].to;
+            rc = build_phf(t, edges, (int32_t)n_edges, err, err_len);
+        }
+    }
+    free(st); free(mem); free(edges); free(elems); free(poff); free(plen);
+    if (oom) { set_err(err, err_len, "out of memory (%ld states)", (long)n_states); rc = PFAC_E_NOMEM; }
+    if (rc) { pfac_table_free(t); pfac_outputs_free(o); return rc; }
+    *out = t;
+    *outs = o;
+    return PFAC_OK;
+}
+
+int pfac_table_build_mem_charclass(const void *patterns, size_t n_bytes, int width, pfac_table **out, pfac_outputs **outputs,
+                                   char *err, size_t err_len) {
+    if (!patterns || !out || !outputs) return PFAC_E_ARG;
+    *out = NULL; *outputs = NULL;
+    if (!is_pow2(width) || width > PFAC_COL_MAX) { set_err(err, err_len, "PHF width %ld must be a power of two <= 4096", width); return PFAC_E_ARG; }
+    return build_charclass_mem((const unsigned char *)patterns, n_bytes, width, out, outputs, err, err_len);
+}
+
+int pfac_table_build_file_charclass(const char *pattern_file, int width, pfac_table **out, pfac_outputs **outputs, char *err,
+                                    size_t err_len) {
+    if (!pattern_file || !out || !outputs) return PFAC_E_ARG;
+    *out = NULL; *outputs = NULL;
+    FILE *f = fopen(pattern_file, "rb");
+    if (!f) { if (err && err_len) snprintf(err, err_len, "cannot open pattern file %s", pattern_file); return PFAC_E_IO; }
+    size_t cap = 1 << 16, n = 0;
+    unsigned char *img = (unsigned char *)malloc(cap);
+    while (img) {
+        n += fread(img + n, 1, cap - n, f);
+        if (n < cap) break;
+        cap *= 2;
+        img = (unsigned char *)realloc(img, cap);
+    }
+    const int io_error = ferror(f);
+    fclose(f);
+    if (!img) { set_err(err, err_len, "out of memory (%ld bytes of pattern file)", (long)n); return PFAC_E_NOMEM; }
+    if (io_error) { free(img); if (err && err_len) snprintf(err, err_len, "cannot read pattern file %s", pattern_file); return PFAC_E_IO; }
+    const int rc = pfac_table_build_mem_charclass(img, n, width, out, outputs, err, err_len);
+    free(img);
+    return rc;
+}
+
+/* One line per (record, pattern that ends in the record's final state), patterns in ascending id. */
+int64_t pfac_emit_records_multi(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const pfac_outputs *outs) {
+    if (!file || (!rec && n) || !outs) return PFAC_E_ARG;
+    FILE *f = (FILE *)file;
+    enum { CHUNK = 1 << 14, LINE_MAX_BYTES = 64 };
+    size_t cap = (size_t)CHUNK * LINE_MAX_BYTES;
+    char *buf = (char *)malloc(cap);
+    if (!buf) return PFAC_E_NOMEM;
+    int64_t total = 0;
+    char *p = buf;
+    for (uint64_t k = 0; k < n; k++) {
+        if (rec[k].state >= (uint32_t)outs->n_states) { free(buf); return PFAC_E_ARG; }
+        for (int32_t j = outs->first[rec[k].state]; j < outs->first[rec[k].state + 1]; j++) {
+            if ((size_t)(p - buf) + LINE_MAX_BYTES > cap) {
+                if (fwrite(buf, 1, (size_t)(p - buf), f) != (size_t)(p - buf)) { free(buf); return PFAC_E_IO; }
+                total += p - buf;
+                p = buf;
+            }
+            memcpy(p, "At position ", 12); p += 12;
+            p = put_uint(p, base + rec[k].pos, 4);
+            memcpy(p, ", match pattern ", 16); p += 16;
+            p = put_uint(p, (uint64_t)outs->ids[j], 1);
+            *p++ = '\n';
+        }
+    }
+    if (fwrite(buf, 1, (size_t)(p - buf), f) != (size_t)(p - buf)) { free(buf); return PFAC_E_IO; }
+    total += p - buf;
+    free(buf);
+    return total;
+}

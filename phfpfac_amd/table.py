@@ -75,6 +75,30 @@ class PfacTable:
         return cls(ptr)
 
     @classmethod
+    def from_charclass(cls, patterns, width: int = 256) -> "PfacTable":
+        """Character-class pattern file (path) or image (bytes): single characters and ``[...]`` / ``[^...]`` classes
+        with ``l-r`` ranges, escape-aware (charset_table_reorder.c:45-168).  The table's final states can stand for
+        several patterns: ``out_first`` / ``out_ids`` list them (``idmap`` holds the first); print with
+        ``emit_records_multi``."""
+        from ._ffi import COutputs
+        L = host_lib()
+        ptr, optr = C.POINTER(CTable)(), C.POINTER(COutputs)()
+        err = C.create_string_buffer(256)
+        if isinstance(patterns, (bytes, bytearray)):
+            buf = C.create_string_buffer(bytes(patterns), len(patterns))
+            rc = L.pfac_table_build_mem_charclass(buf, len(patterns), int(width), C.byref(ptr), C.byref(optr), err, 256)
+        else:
+            rc = L.pfac_table_build_file_charclass(os.fsencode(patterns), int(width), C.byref(ptr), C.byref(optr), err, 256)
+        if rc:
+            raise PfacError(rc, err.value.decode(errors="replace"))
+        t = cls(ptr)
+        o = optr.contents
+        t.out_first = np.ctypeslib.as_array(o.first, (o.n_states + 1,)).copy()
+        t.out_ids = np.ctypeslib.as_array(o.ids, (max(int(t.out_first[-1]), 1),))[: int(t.out_first[-1])].copy()
+        L.pfac_outputs_free(optr)
+        return t
+
+    @classmethod
     def from_blob(cls, blob: np.ndarray) -> "PfacTable":
         L = host_lib()
         blob = np.ascontiguousarray(blob, dtype=np.int32)
@@ -201,4 +225,28 @@ def emit_packed(path, words: np.ndarray, tile_index: np.ndarray, idmap, base: in
         libc.fclose(f)
     if n < 0:
         raise PfacError(int(n), "pfac_emit_packed")
+    return int(n)
+
+
+def emit_records_multi(path, records: np.ndarray, table: "PfacTable", base: int = 0) -> int:
+    """Text for a character-class table: one line per (record, pattern that ends in the record's final state)."""
+    from ._ffi import COutputs
+    L = host_lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+    first = np.ascontiguousarray(table.out_first, dtype=np.int32)
+    ids = np.ascontiguousarray(table.out_ids if table.out_ids.size else np.zeros(1, np.int32), dtype=np.int32)
+    o = COutputs(int(first.size - 1), first.ctypes.data_as(C.POINTER(C.c_int32)), ids.ctypes.data_as(C.POINTER(C.c_int32)))
+    f = libc.fopen(os.fsencode(path), b"wb")
+    if not f:
+        raise PfacError(-2, f"cannot open {path}")
+    try:
+        n = L.pfac_emit_records_multi(f, records.ctypes.data, records.size, int(base), C.byref(o))
+    finally:
+        libc.fclose(f)
+    if n < 0:
+        raise PfacError(int(n), "pfac_emit_records_multi")
     return int(n)
