@@ -93,6 +93,10 @@ constexpr int D1_N2_MAX = 2048;            // ... so at most this many depth-2 s
 #define PFAC_L2F_UNROLL 1
 #endif
 constexpr int L2F_UNROLL = PFAC_L2F_UNROLL;  // survivors classified per trip of the level-2 lookup loop
+#ifndef PFAC_MASK_GATHERS
+#define PFAC_MASK_GATHERS 1
+#endif
+constexpr bool MASK_GATHERS = PFAC_MASK_GATHERS != 0;   // fused walks: exec-mask the table gathers of dead walkers
 constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
 #ifndef PFAC_NBUF
@@ -409,9 +413,10 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
 #pragma unroll
             for (int w = 0; w < NWALK; w++) {
                 ic[w] = min((unsigned)idx[w], (unsigned)ht_size - 1u);
-                if (NWALK == 4) {
-                    // the dense-match regime waits on the memory pipeline, not on instruction issue: dead lanes
-                    // stay out of the gather (every lane of a gather costs the texture path an address cycle)
+                if (NWALK == 4 || MASK_GATHERS) {
+                    // dead lanes stay out of the gather: every lane of a gather costs the texture path an address
+                    // cycle (64 per wave-instruction, against 16 for a coalesced 1 KiB load), and a round's later
+                    // steps have few walkers left
                     e[w] = make_int4(-1, -1, 0, 0);
                     if (go[w]) e[w] = T4[ic[w]];
                 } else {
@@ -671,6 +676,12 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
         return wrun + totals[0] + totals[1];
     }
     constexpr unsigned RW = WAVE * NWALK;      // survivors per round
+#ifdef PFAC_TRACE_BUILD
+    unsigned long long tp_round = 0, tp_n = 0, tp_t0 = __builtin_amdgcn_s_memrealtime();
+#define TP_ROUND(call) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); call; tp_round += __builtin_amdgcn_s_memrealtime() - t_; tp_n++; } while (0)
+#else
+#define TP_ROUND(call) do { call; } while (0)
+#endif
 #pragma unroll
     for (int j = 0; j < MSUBS; j++) {
         const unsigned mask = keep[j];
@@ -702,7 +713,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             wave_lds_sync();
             unsigned h = 0;
             for (; h + RW <= tail; h += RW)
-                wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun);
+                TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun)));
             if (h) {                               // move the < RW left-overs to the front
                 const unsigned rem = tail - h;
                 unsigned short v[NWALK];
@@ -716,7 +727,14 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             }
         }
     }
-    if (tail) wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun);
+    if (tail) TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun)));
+#ifdef PFAC_TRACE_BUILD
+    if (!DIRECT && a.dbg && blockIdx.x < 8 && lane == 0 && (threadIdx.x >> 6) == 0) {
+        // compute wave 0 of the first 8 workgroups: accumulated over the launch (slot 31 of the block's first row)
+        unsigned long long *acc = a.dbg + (size_t)blockIdx.x * 64 * 32 + 10;      // columns 10..14 of the block's row 0
+        acc[0] += tp_round; acc[1] += tp_n; acc[2] += __builtin_amdgcn_s_memrealtime() - tp_t0; acc[3] += 1; acc[4] += tail;
+    }
+#endif
     return wrun;
 }
 

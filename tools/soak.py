@@ -1,6 +1,8 @@
 """GPU soak: many back-to-back scans of random lengths / offsets over resident inputs, two slots in flight, every
-count checked against a closed form (text input has period 402) or against a reference scan of the same range.
-Looks for rare protocol failures (look-back timeouts surface as PFAC_E_INTERNAL) and count drift."""
+count checked against a closed form (text input has period 402); scans below 1 MiB also have their expanded records
+compared with the CPU oracle record for record (heap placement, tile index, chunk boundaries).
+Looks for rare protocol failures (timeouts surface as PFAC_E_INTERNAL), count drift and misplaced records.
+usage: soak.py [seconds] [seed] [own]      ("own": the two slots keep their own streams -> two grids at once)"""
 import os
 import sys
 import time
@@ -48,13 +50,15 @@ def expected(start, n_owned, n_avail):
 
 
 with GpuMatcher(0, 2) as g:
-    g.set_stream(1, g.stream_handle(0))
+    if "own" not in sys.argv:
+        g.set_stream(1, g.stream_handle(0))
     g.load_table(table)
     g.fill_tiled(buf, N, para)
     g.reserve(0, 0, N // 8)
     g.reserve(1, 0, N // 8)
     t0 = time.time()
     scans = 0
+    checked = 0
     inflight = []
     while time.time() - t0 < seconds:
         kind = rng.integers(0, 4)
@@ -78,9 +82,16 @@ with GpuMatcher(0, 2) as g:
             want = expected(st, no, na)
             if cnt != want or over:
                 raise SystemExit(f"MISMATCH scan {scans}: start {st} n_owned {no} n_avail {na}: got {cnt} want {want} overflow {over}")
+            if no < (1 << 20):
+                rec = g.records_to_host(cnt, slot=s_)
+                opos, oids = o.scan_spec(tiled_bytes(na, para, phase=st % 402))
+                keep = opos < no
+                if not (np.array_equal(rec["pos"].astype(np.int64), opos[keep]) and np.array_equal(table.idmap[rec["state"]], oids[keep])):
+                    raise SystemExit(f"RECORD MISMATCH scan {scans}: start {st} n_owned {no} n_avail {na}")
+                checked += 1
         scans += 1
     for s_, st, no, na in inflight:
         cnt, over = g.scan_finish(s_)
         assert cnt == expected(st, no, na) and not over
-    print(f"soak ok: {scans} scans in {time.time() - t0:.1f} s, all counts exact")
+    print(f"soak ok: {scans} scans in {time.time() - t0:.1f} s, all counts exact, {checked} scans compared record for record")
 o.close()

@@ -14,6 +14,10 @@ N = 1 << 30
 name = sys.argv[1] if len(sys.argv) > 1 else "experimentpattern"
 kind = sys.argv[2] if len(sys.argv) > 2 else "text"
 path = os.path.join(DATA, name)
+if "+" in name:
+    import tempfile
+    path = os.path.join(tempfile.mkdtemp(), "all.pat")
+    open(path, "wb").write(b"".join(open(os.path.join(DATA, p), "rb").read() for p in name.split("+")))
 if name.endswith(".gz"):
     import gzip, tempfile
     path = os.path.join(tempfile.mkdtemp(), name[:-3]); open(path, "wb").write(gzip.open(os.path.join(DATA, name), "rb").read())
@@ -24,6 +28,7 @@ with GpuMatcher(0, 1) as g:
     if kind == "rand": g.fill_random(buf, N, 0x5048465046414331)
     else: g.fill_tiled(buf, N, para)
     g.reserve(0, 0, N // 8)
+    g.scan_resident(N, N, d_input=buf)         # sizes the record heap (and lets the staging mode adapt)
     for _ in range(3):
         g.scan_async(N, N, d_input=buf); n, _ = g.scan_finish(0)
     print(name, kind, "kernel ms", g.elapsed_ms(0), "matches", n, g.info())
@@ -44,3 +49,8 @@ for b in (0, 3):
               "compact + walk + stage": np.mean([r_[7] - r_[6] for r_ in rows]), "post + emit": np.mean([r_[8] - r_[7] for r_ in rows])}
         per = np.mean(np.diff([x[r, 4] for r in range(4, 60) if x[r, 4]]))
         print("  wave 0 mean phases (us):", {k: round(v / 100, 2) for k, v in ph.items()}, "round", round(per / 100, 2))
+
+acc = d[:, 0, 10:15].sum(axis=0).astype(float)
+if acc[3]:
+    print(f"tile_pass of compute wave 0 (8 workgroups, whole launch): {acc[3]:.0f} tiles with FIFO work, {acc[1] / acc[3]:.2f} rounds per tile, "
+          f"{acc[0] / max(acc[1], 1) / 100:.2f} us per round, {acc[2] / acc[3] / 100:.2f} us per tile_pass (rounds {acc[0] / acc[3] / 100:.2f} us), last-round entries {acc[4] / acc[3]:.1f}")
