@@ -32,14 +32,15 @@
  *            or L2 (large: 2-4 walks per lane, slots fused with the next state's r[] so a step is one gather);
  *            final states are recorded as they are met (mk.cu:49-71); a round without deep entries skips the walk
  *   stage    records (pos:12 | state:20) go to an LDS staging buffer in (position, length) order
- *   order    per-wave counts -> coordinator -> batch aggregate -> decoupled look-back over batches
- *            (8-byte {flag,value} words, relaxed agent-scope atomics), pipelined over three rounds;
- *            the coordinator writes every wave's first record index back to LDS
- *   emit     two rounds later the wave copies its staged words to global memory, 16 B per lane, and stores the
- *            tile's first record index -- globally sorted by (position, pattern length), the reference's output
- *            order (main.cc:341-349).  Tiles with more records than the staging buffer holds are
- *            re-walked writing straight to global memory; "dense mode" (one big staging buffer,
- *            synchronous emission) takes over when most tiles are like that.
+ *   place    per-wave counts -> coordinator, which places the round's tiles back to back in the workgroup's current
+ *            CHUNK of the record heap (one atomic on the heap cursor per chunk, the next chunk always on order: no
+ *            workgroup ever waits for another), writes every wave's first record index back to LDS and the tiles'
+ *            index words (first record | count << 40) to memory -- all in the round the counts came in
+ *   emit     one round later the wave copies its staged words to the heap, 16 B per lane.  Walking the tile index
+ *            in order gives the records sorted by (position, pattern length), the reference's output order
+ *            (main.cc:341-349).  Tiles with more records than the staging buffer holds are re-walked writing
+ *            straight to the heap; "dense mode" (one big staging buffer, synchronous emission) takes over when most
+ *            tiles are like that.
  */
 #include <hip/hip_runtime.h>
 
@@ -114,10 +115,9 @@ constexpr int PW_FIXED_DENSE = WTILE + QCAP * 2 + CAPW_DENSE * 4;
 // Batch tickets: one address sustains ~85 M atomics/s, and at 4 TB/s with 60 KiB per ticket the workgroups ask for
 // 65 M/s -- the single counter was the floor of the whole kernel (3.9 us per round with the scan compiled out).  So
 // there are TICKET_WAYS counters, 256 bytes apart: workgroup j draws from counter j % ways and holds batches
-// ticket * ways + j % ways.  Ids stay monotone per workgroup (it leaves when ITS counter runs past the end), every
-// batch below the end is drawn by somebody as long as every residue class has a workgroup (ways <= grid), and a
-// look-back that meets a batch nobody has drawn yet simply sees "not published" and polls: the residue class with
-// the smallest undrawn batch never waits for a larger one, so somebody always makes progress.
+// ticket * ways + j % ways.  Ids stay monotone per workgroup (it leaves when ITS counter runs past the end) and every
+// batch below the end is drawn by somebody as long as every residue class has a workgroup (ways <= grid).  Nothing
+// waits for a batch: a workgroup's record placement depends on no other workgroup (see "Record placement").
 #ifndef PFAC_TICKET_WAYS
 #define PFAC_TICKET_WAYS 4
 #endif
@@ -200,15 +200,6 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x) {
     return x;
 }
 __device__ __forceinline__ unsigned bcast_last(unsigned x) { return __builtin_amdgcn_readlane(x, WAVE - 1); }
-// Sum of a 62-bit value over the wave without LDS round trips: three DPP scans over 24/24/14-bit slices (the
-// coordinator sums on its critical path every round; six dependent ds_bpermute pairs cost it ~0.3 us).
-__device__ __forceinline__ unsigned long long wave_sum62(unsigned long long x) {
-    const unsigned lo = (unsigned)x & 0xFFFFFFu, mid = (unsigned)(x >> 24) & 0xFFFFFFu, hi = (unsigned)(x >> 48);
-    const unsigned long long slo = bcast_last(wave_incl_scan(lo)), smid = bcast_last(wave_incl_scan(mid)),
-                             shi = bcast_last(wave_incl_scan(hi));
-    return slo + (smid << 24) + (shi << 48);
-}
-
 // LDS written by some lanes of a wave and read by others of the SAME wave:
 // the LDS executes one wave's instructions in order; this keeps the compiler
 // from moving accesses across and drains lgkmcnt.
@@ -220,15 +211,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 // Workgroup organisation.  A workgroup = NC compute waves + 1 coordinator wave, and proceeds in
 // ROUNDS: in round r compute wave c scans tile  batch(r) * NC + c.  Batches are handed out in order by
 // one global atomic per round (a ticket per 4 KiB tile would hit the ~88 M atomics/s an address
-// sustains on MI355X and cap the scan at 0.36 TB/s), taken two rounds ahead by the coordinator.
-// The coordinator also sums the round's per-wave match counts, publishes the batch aggregate and
-// runs the decoupled look-back over BATCHES (a few hundred are in flight chip-wide, so the window is
-// short), while the compute waves are already scanning the next round; they pick the batch's
-// record base up from LDS when they emit, one round later.  No workgroup barrier in the loop.
-// With TICKET_WAYS counters batch ids are monotone per workgroup and per residue class only: a look-back may meet
-// a batch nobody has drawn yet and polls it; liveness needs a RESIDENT workgroup in every residue class (one
-// workgroup per CU on a GPU this launch can fill gives that; otherwise the bounded spins end the scan with
-// PFAC_E_INTERNAL instead of hanging).  Nothing depends on dispatch order or placement.
+// sustains on MI355X and cap the scan at 0.36 TB/s), taken AHEAD rounds ahead by the coordinator.
+// The coordinator also sums the round's per-wave match counts and places the round's tiles in the
+// workgroup's chunk of the record heap, while the compute waves are already scanning the next round;
+// they pick their first record index up from LDS when they emit, one round later.  No workgroup barrier
+// in the loop, and no wait on any other workgroup: nothing depends on dispatch order, residency or
+// placement (several grids of this kernel may run at once -- gphf's slots do).  The waits inside a
+// workgroup (rings below) are bounded; a timeout ends the scan with PFAC_E_INTERNAL instead of hanging.
 //
 // LDS header (unsigned words), rings of 8 rounds indexed by r & 7:
 constexpr int RING = 8;
@@ -824,7 +813,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int nc = (int)(blockDim.x >> 6) - 1;             // compute waves; wave nc coordinates
 
-    // ---- the control words of the slot's NEXT scan (ticket + look-back words of its other buffer) are zeroed here,
+    // ---- the control header of the slot's NEXT scan (ticket counters, flags, heap cursor of its other buffer) is zeroed here,
     // spread over the whole grid: the next launch on the stream starts after this one has ended
     for (unsigned i = blockIdx.x * blockDim.x + tid; i < a.zero_vec; i += gridDim.x * blockDim.x)
         a.zero_next[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -2079,7 +2068,7 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
     if (s.h_ctl[2] != 0) {
         s.clean[0] = s.clean[1] = false;       // whatever state the control headers are in: zero them before the next scan
         return fail(ctx, PFAC_E_INTERNAL, "scan kernel reported a timeout (flags " + std::to_string(s.h_ctl[2]) +
-                                          ": 1 look-back, 4 arrivals, 8 record base, 16 batch ring)");
+                                          ": 4 arrivals, 8 record base, 16 batch ring)");
     }
     // Staging mode for the NEXT scans of this context: when more than a quarter of the tiles held more matches
     // than the small (three-buffer) staging area takes, go dense (one big buffer, emitted at once, no second
