@@ -16,7 +16,13 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun_out/ keeps the files of earlier runs of the same tag: only the most recent one counts."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 shutil.copyfile(ks, os.path.join(dst, f"{rnd}_kernel_stats{suffix}.csv"))
 out = {"kernel_source_sha256": hashlib.sha256(open(os.path.join(root, "phfpfac_amd", "csrc", "pfac_hip.hip"), "rb").read()).hexdigest()}
 try:
@@ -28,7 +34,7 @@ try:
     n_bytes = b["config"]["bytes_per_gpu"]
 except (IndexError, OSError, ValueError, KeyError):
     n_bytes = 1 << 30
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+for f in sorted(filter(None, (newest(os.path.join(d, "*", "*_counter_collection.csv")) for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "pfac_scan_kernel" in r["Kernel_Name"]:
@@ -58,9 +64,9 @@ for row in csv.DictReader(open(ks)):
                                                    "avg_ns": float(row["AverageNs"]), "max_ns": float(row["MaxNs"])})
 # per-launch durations from the kernel trace: the --stats average covers EVERY launch of the command (setup, clock
 # settling, warm-up, timed steps); bench.py's roofline uses the timed steps only = the last `steps` launches
-kt = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+kt = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
 if kt:
-    rows = [r for r in csv.DictReader(open(kt[0])) if "pfac_scan_kernel" in r.get("Kernel_Name", "")]
+    rows = [r for r in csv.DictReader(open(kt)) if "pfac_scan_kernel" in r.get("Kernel_Name", "")]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     if dur:
