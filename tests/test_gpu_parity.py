@@ -103,11 +103,16 @@ def test_dictionary_dense_mode_kernels(width, env, resolve, monkeypatch):
 @pytest.mark.parametrize("env", [{"PFAC_FORCE_L2": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_DENSE": "1"},
                                  {"PFAC_FORCE_L2": "1", "PFAC_NO_D1": "1", "PFAC_DENSE": "1"},
                                  {"PFAC_FORCE_L2": "1", "PFAC_NO_FUSE": "1"}, {"PFAC_NWB": "5", "PFAC_DENSE": "1"},
-                                 {"PFAC_NWB": "3"}, {"PFAC_NO_D1": "1"}])
+                                 {"PFAC_NWB": "3"}, {"PFAC_NO_D1": "1"},
+                                 {"PFAC_WIDE": "1"},                      # 8-byte records in the heap (automata beyond 2^20 final states)
+                                 {"PFAC_WIDE": "1", "PFAC_FORCE_L2": "1", "PFAC_DENSE": "1"},
+                                 {"PFAC_L2F": "0"}, {"PFAC_L2F": "2"},    # level-2 filter off / lookup form where the SWAR form applies
+                                 {"PFAC_L2F": "2", "PFAC_FORCE_L2": "1"}, {"PFAC_NO_SECF": "1", "PFAC_FORCE_L2": "1"}])
 @pytest.mark.parametrize("case", ["exp_x_1M_s1_w256", "xaa_x_1M_s1_w256", "all_x_1M_s3_w1024"])
 def test_golden_under_every_kernel_variant(case, env, resolve, tmp_path, monkeypatch):
-    """The tuning knobs select other kernel instantiations / LDS layouts (tables through L2, fused slots, four walks per
-    lane, dense staging, fewer waves, no dense rows); the golden files must come out of every one of them."""
+    """The tuning knobs select other kernel instantiations / LDS layouts / record forms (tables through L2, fused slots,
+    four walks per lane, dense staging, fewer waves, no dense rows, 8-byte records, every form of the level-2 filter);
+    the golden files must come out of every one of them."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     c = FP["cases"][case]
