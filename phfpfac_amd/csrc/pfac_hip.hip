@@ -1710,6 +1710,15 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     if (getenv("PFAC_NWB") && atoi(getenv("PFAC_NWB")) > 0 && atoi(getenv("PFAC_NWB")) < nwb) nwb = atoi(getenv("PFAC_NWB"));
     if (nwb < 2) return fail(ctx, PFAC_E_INTERNAL, "LDS budget cannot hold one compute wave");
     ctx->waves_per_block = nwb;
+    // LDS that no further wave fits into goes to the staging buffers: a tile may then hold more records (up to 1024
+    // per 4 KiB) before it has to be walked a second time
+    unsigned stage_cap = (unsigned)CAPW;
+    if (!getenv("PFAC_NWB")) {
+        const int spare = (LDS_TOTAL - ctx->shared_bytes) / (nwb - 1) - ctx->pw_bytes;      // bytes per compute wave
+        const int extra = spare > 0 ? (spare / (NBUF * 4)) & ~15 : 0;                       // records per staging buffer
+        stage_cap = (unsigned)(CAPW + extra) > 1024u ? 1024u : (unsigned)(CAPW + extra);
+        ctx->pw_bytes += (int)(stage_cap - CAPW) * NBUF * 4;
+    }
     ctx->lds_bytes = ctx->shared_bytes + (nwb - 1) * ctx->pw_bytes;
     // one workgroup per CU: ask for more than half of the LDS so two never share a CU while another idles
     if (ctx->lds_bytes < LDS_TOTAL / 2 + 256) ctx->lds_bytes = LDS_TOTAL / 2 + 256;
@@ -1719,7 +1728,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->root_byte = (unsigned)rb * 0x01010101u;
     ctx->root_state = s0_host[rb];
     ctx->packed = ctx->num_final <= (1 << PACK_STATE_BITS) && !getenv("PFAC_WIDE");   // PFAC_WIDE: test knob, 8-byte records
-    ctx->stage_cap = ctx->packed ? (unsigned)CAPW : 0u;
+    ctx->stage_cap = ctx->packed ? stage_cap : 0u;
     // dense-mode layout
     ctx->pw_bytes_d = (int)align_up((size_t)PW_FIXED_DENSE + ctx->halo, 16);
     int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
