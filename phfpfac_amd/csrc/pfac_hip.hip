@@ -1148,7 +1148,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         PFAC_STAMP(trace, 6);
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * a.stage_cap;
-        const unsigned long long cnt = tile_pass<W8, false, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, 0);
+        // (a tile nothing survives in -- most tiles of a sparse pattern set -- goes straight to posting its zero)
+        const unsigned long long cnt = !__any((keep[0] | keep[1]) != 0u) ? 0ull :
+            tile_pass<W8, false, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, 0);
         PFAC_STAMP(trace, 7);
 #ifdef PFAC_TRACE_BUILD
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
