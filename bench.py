@@ -374,7 +374,8 @@ def main():
         if headline:
             # What a consumer of ONE ordered record stream pays on top of the scan, reported next to the timed value:
             # heap -> sorted 8-byte records on the device (expand), and (N > 1) their ordered gather on rank 0.
-            _, n_tiles, used = g.scan_format(1)
+            rec_b, n_tiles, used = g.scan_format(1)
+            res["rec_bytes"] = rec_b
             wide = torch.empty(max(cnt, 1), dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -407,7 +408,7 @@ def main():
     traffic, traffic_note = (None, "measured for the headline workload at 1 GiB only")
     if args.workload == HEADLINE and per == GIB:
         traffic, traffic_note = committed_traffic()
-    rec_bytes = 4 if res["table"].num_final <= (1 << 20) else 8
+    rec_bytes = res["rec_bytes"]
     out = {
         "metric": "input GB/s scanned", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 4),
@@ -418,7 +419,7 @@ def main():
                    "grid_blocks": res["info"]["grid_blocks"], "lds_bytes": res["info"]["lds_bytes"],
                    "parallelism": f"input-sharded x{world}, halo {res['table'].halo} B",
                    "matches_per_step": res["matches"], "record_bytes": rec_bytes,
-                   "record_layout": "heap of compact records + ordered tile index (8 B per 4 KiB tile)",
+                   "record_layout": "heap of compact records (pos:12 | final state, as wide as the automaton needs) + ordered tile index (8 B per 4 KiB tile)",
                    "parity": "records of the first 4 MiB per rank == CPU oracle, bit-exact",
                    "settle_launches": res["settle"], "cold_first20_gbs": round(res["n_owned"] / (res["cold_ms"] * 1e-3) / 1e9, 1),
                    "expand_ms": round(res["expand_ms"], 3),

@@ -145,14 +145,14 @@ typedef struct pfac_record {
     uint32_t state;     /* final state reached (== index into idmap) */
 } pfac_record;
 /*
- * On the DEVICE the scan writes the COMPACT form of the same list (half the HBM and PCIe bytes): one 32-bit word per
- * match,  (pos & 4095) | state << 12,  into a record HEAP, plus an ordered TILE INDEX: the records of 4 KiB input
- * tile t are the PFAC_TIX_COUNT(tile_index[t]) words that start at word PFAC_TIX_FIRST(tile_index[t]), in (position,
- * pattern length) order, with  pos = t * 4096 + (word & 4095).  Walking the index in tile order yields the reference's
- * output order; the heap itself has small gaps and no global order (a workgroup fills chunks of it with the tiles it
- * scans -- a globally contiguous array would cost a chip-wide prefix over batches that are still being scanned).
- * Automata with more than 2^20 final states keep 8-byte pfac_record in the heap (pfac_scan_format tells which).
- * pfac_records_d2h / pfac_records_expand deliver ONE sorted pfac_record array either way.
+ * On the DEVICE the scan writes the COMPACT form of the same list: one word per match,  (pos & 4095) | state << 12,
+ * as wide as the automaton needs -- 16 bits for at most 16 final states, 32 bits up to 2^20, else an 8-byte
+ * pfac_record (pfac_scan_format tells which) -- into a record HEAP, plus an ordered TILE INDEX: the records of 4 KiB
+ * input tile t are the PFAC_TIX_COUNT(tile_index[t]) words that start at word PFAC_TIX_FIRST(tile_index[t]), in
+ * (position, pattern length) order, with  pos = t * 4096 + (word & 4095).  Walking the index in tile order yields the
+ * reference's output order; the heap itself has small gaps and no global order (a workgroup fills chunks of it with
+ * the tiles it scans -- a globally contiguous array would cost a chip-wide prefix over batches that are still being
+ * scanned).  pfac_records_d2h / pfac_records_expand deliver ONE sorted pfac_record array whatever the form.
  */
 #define PFAC_TILE_BYTES 4096
 #define PFAC_PACKED_POS(word) ((uint32_t)(word) & 4095u)
@@ -170,9 +170,9 @@ int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uin
                              int n_threads);
 /* The same text straight from the compact device form (record heap + tile index as pfac_records_d2h_packed
  * delivers them), tiles in order: position = base + t * 4096 + PFAC_PACKED_POS(word), pattern =
- * idmap[PFAC_PACKED_STATE(word)].  n_threads < 2: serial. */
-int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_index, uint64_t n_tiles, uint64_t base,
-                         const int32_t *idmap, int n_threads);
+ * idmap[PFAC_PACKED_STATE(word)]; record_bytes = 2 or 4 as pfac_scan_format reports.  n_threads < 2: serial. */
+int64_t pfac_emit_packed(void *file, const void *words, int record_bytes, const uint64_t *tile_index, uint64_t n_tiles,
+                         uint64_t base, const int32_t *idmap, int n_threads);
 /* Merge of per-partition match lists, replaces main.cc:304-324.  lists[k] (counts[k] records, sorted by
  * position as the scan emits them) comes from partition k of pfac_table_build_file_part(); the result is
  * ordered by (position, partition) -- i.e. by (position, pattern length), the reference's output order -- and
@@ -229,7 +229,7 @@ int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, u
  *             start in the owned range may read up to n_avail (the halo of
  *             max_pat_len-1 bytes that belongs to the next shard) and never beyond
  *   d_records device pointer for the record heap, 16-B aligned, NULL = the slot's;
- *             capacity x 4 bytes are written in the compact form, capacity x 8 in the wide one
+ *             at most capacity x 8 bytes are written (capacity x 2 or x 4 in the compact forms)
  *   capacity  records the heap holds.  It needs some slack over the match count (chunks a workgroup has not
  *             filled: at most capacity/16, plus gaps below 1 %); the match count is exact even when the
  *             heap overflows, and pfac_scan_capacity_hint() then says what to reserve
@@ -250,16 +250,17 @@ int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms);
  * cudaMemcpy D2H, master_kernel.cu:428).  Asynchronous; pfac_slot_sync() completes it. */
 int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record *host, uint64_t first, uint64_t n);
 int pfac_slot_sync(pfac_ctx *ctx, int slot);
-/* Record form of the slot's last finished scan: *packed = 1 compact words, 0 pfac_record in the heap; *n_tiles =
- * tiles scanned = entries of the tile index; *used = heap records in use (<= capacity unless it overflowed). */
-int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles, uint64_t *used);
+/* Record form of the slot's last finished scan: *record_bytes = 2 or 4 (compact words) or 8 (pfac_record in the
+ * heap); *n_tiles = tiles scanned = entries of the tile index; *used = heap records in use (<= capacity unless it
+ * overflowed). */
+int pfac_scan_format(pfac_ctx *ctx, int slot, int *record_bytes, uint64_t *n_tiles, uint64_t *used);
 /* Records [first, first+n) of the slot's last scan, SORTED, as pfac_record in DEVICE memory (d_out, 8-B aligned), on
  * the slot's stream -- for consumers that stay on the GPU (the RCCL record gather). */
 int pfac_records_expand(pfac_ctx *ctx, int slot, const void *d_records, uint64_t first, uint64_t n, pfac_record *d_out);
-/* D2H of the compact form itself: heap words [0, n_words) (n_words = *used of pfac_scan_format) and the n_tiles
- * entries of the tile index (4 bytes per match over PCIe instead of 8; pfac_emit_packed() prints from it).
- * PFAC_E_STATE when the last scan was not compact. */
-int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n_words,
+/* D2H of the compact form itself: heap words [0, n_words) (n_words = *used of pfac_scan_format; record_bytes each)
+ * and the n_tiles entries of the tile index (2 or 4 bytes per match over PCIe instead of 8; pfac_emit_packed() prints
+ * from it).  PFAC_E_STATE when the last scan was not compact. */
+int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, void *host_words, uint64_t n_words,
                             uint64_t *host_tile_index);
 
 /* Order-independent 64-bit checksum of ALL records of the slot's last scan (sum over records of

@@ -120,7 +120,7 @@ def host_lib() -> C.CDLL:
         L.pfac_emit_records.restype = C.c_int64
         L.pfac_emit_records_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.pfac_emit_records_mt.restype = C.c_int64
-        L.pfac_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        L.pfac_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.pfac_emit_packed.restype = C.c_int64
         OP = C.POINTER(COutputs)
         L.pfac_table_build_file_charclass.argtypes = [C.c_char_p, C.c_int, C.POINTER(TP), C.POINTER(OP), C.c_char_p, C.c_size_t]

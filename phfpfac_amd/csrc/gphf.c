@@ -47,7 +47,8 @@ typedef struct {
     uint64_t base;          /* global offset of the chunk's first owned byte */
     uint64_t n_owned, n_avail;
     pfac_record *rec;       /* host copy of the chunk's records: 8-byte form (automata beyond 2^20 final states) ... */
-    uint32_t *words;        /* ... or the compact form: record heap + tile index (pfac.h) */
+    void *words;            /* ... or the compact form: record heap (16- or 32-bit words) + tile index (pfac.h) */
+    int word_bytes;
     uint64_t *tix;
     uint64_t n_tiles;
     uint64_t n_rec;
@@ -155,11 +156,12 @@ static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap
     float ms = 0;
     if (pfac_scan_elapsed_ms(ctx, slot, &ms) == 0) w->kernel_ms += ms;
     c->n_rec = n;
-    int packed = 0;
+    int rec_bytes = 0;
     uint64_t used = 0;
-    if ((rc = pfac_scan_format(ctx, slot, &packed, &c->n_tiles, &used))) return fail(w, ctx, rc, "format");
-    if (packed) {                                   /* 4 bytes per match over PCIe; the emitter prints from this form */
-        c->words = (uint32_t *)malloc((used ? used : 1) * sizeof(uint32_t));
+    if ((rc = pfac_scan_format(ctx, slot, &rec_bytes, &c->n_tiles, &used))) return fail(w, ctx, rc, "format");
+    if (rec_bytes < 8) {                            /* 2 or 4 bytes per match over PCIe; the emitter prints from this form */
+        c->word_bytes = rec_bytes;
+        c->words = malloc((used ? used : 1) * (size_t)rec_bytes);
         c->tix = (uint64_t *)malloc((c->n_tiles ? c->n_tiles : 1) * sizeof(uint64_t));
         if (!c->words || !c->tix) return fail(w, NULL, PFAC_E_NOMEM, "out of host memory for records");
         if ((rc = pfac_records_d2h_packed(ctx, slot, NULL, c->words, used, c->tix))) return fail(w, ctx, rc, "d2h");
@@ -318,7 +320,7 @@ int main(int argc, char *argv[]) {
         if (!ok) break;
         double e0 = now_ms();
         const int64_t wrote = chunks[k].words
-            ? pfac_emit_packed(fpout, chunks[k].words, chunks[k].tix, chunks[k].n_tiles, chunks[k].base, tab->idmap, emit_threads)
+            ? pfac_emit_packed(fpout, chunks[k].words, chunks[k].word_bytes, chunks[k].tix, chunks[k].n_tiles, chunks[k].base, tab->idmap, emit_threads)
             : pfac_emit_records_mt(fpout, chunks[k].rec, chunks[k].n_rec, chunks[k].base, tab->idmap, emit_threads);
         if (wrote < 0) {
             fprintf(stderr, "write failed\n");

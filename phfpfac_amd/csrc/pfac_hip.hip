@@ -98,6 +98,10 @@ constexpr int L2F_UNROLL = PFAC_L2F_UNROLL;  // survivors classified per trip of
 #define PFAC_MASK_GATHERS 1
 #endif
 constexpr bool MASK_GATHERS = PFAC_MASK_GATHERS != 0;   // fused walks: exec-mask the table gathers of dead walkers
+#ifndef PFAC_LOAD_AUX
+#define PFAC_LOAD_AUX 0
+#endif
+constexpr int LOAD_AUX = PFAC_LOAD_AUX;    // cache policy of the tile loads (0 default, 2 = nt: the input is read once)
 constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
 // per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
 #ifndef PFAC_NBUF
@@ -133,11 +137,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct ScanArgs {
     const unsigned char *in;
     unsigned long long n_owned, n_avail;
-    void *out;                            // the record heap; packed: unsigned[out_cap] (pos:12 | state:20); else pfac_record[out_cap]
+    void *out;                            // the record heap: out_cap records of rec_bytes bytes
     unsigned long long out_cap;
     unsigned long long *tile_index;       // [n_tiles]: first record of the tile | its record count << 40
     unsigned chunk;                       // records a workgroup takes from the heap cursor at a time (0: exact allocations only)
-    unsigned packed;                      // record format of this scan (1: 4-byte words + tile_first, 0: 8-byte records)
+    unsigned rec_bytes;                   // record form of this scan: 2 (pos:12 | state:4), 4 (pos:12 | state:20) or 8 (pfac_record)
     const int *s0;
     const int *r;
     const int2 *T;
@@ -503,10 +507,12 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     }
 }
 
-// One record into the global array (the DIRECT paths): a packed word or a wide record.
+// One record into the global array (the DIRECT paths), in the scan's record form.
 __device__ __forceinline__ void put_record(const ScanArgs &a, unsigned long long ri, unsigned tpos, unsigned gpos, unsigned state) {
     if (ri >= a.out_cap) return;
-    if (a.packed) {
+    if (a.rec_bytes == 2) {
+        static_cast<unsigned short *>(a.out)[ri] = (unsigned short)(tpos | (state << 12));
+    } else if (a.rec_bytes == 4) {
         static_cast<unsigned *>(a.out)[ri] = tpos | (state << 12);
     } else {
         pfac_record rec;
@@ -731,6 +737,26 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
 // records (16 bytes) per lane per store, aligned to the record array.
 __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base, int lane) {
     if (cnt == 0) return;
+    if (a.rec_bytes == 2) {
+        // automata with at most 16 final states: the record is the low half of the staged word; eight per 16-byte store
+        unsigned short *out = static_cast<unsigned short *>(a.out);
+        if (base + cnt > a.out_cap) {
+            for (unsigned i = (unsigned)lane; i < cnt; i += WAVE)
+                if (base + i < a.out_cap) out[base + i] = (unsigned short)stage[i];
+            return;
+        }
+        unsigned head = (0u - (unsigned)base) & 7u;
+        head = head < cnt ? head : cnt;
+        if ((unsigned)lane < head) out[base + lane] = (unsigned short)stage[lane];
+        unsigned i = head + 8u * (unsigned)lane;
+        for (; i + 8u <= cnt; i += 8u * WAVE) {
+            const u32x4 v = {(stage[i] & 0xFFFFu) | (stage[i + 1] << 16), (stage[i + 2] & 0xFFFFu) | (stage[i + 3] << 16),
+                             (stage[i + 4] & 0xFFFFu) | (stage[i + 5] << 16), (stage[i + 6] & 0xFFFFu) | (stage[i + 7] << 16)};
+            *reinterpret_cast<u32x4 *>(out + base + i) = v;
+        }
+        for (unsigned k = 0; k < 7u && i + k < cnt; k++) out[base + i + k] = (unsigned short)stage[i + k];   // the last 1..7 (one lane)
+        return;
+    }
     unsigned *out = static_cast<unsigned *>(a.out);
     if (base + cnt > a.out_cap) {              // the record array ends inside this tile: word by word, checked
         for (unsigned i = (unsigned)lane; i < cnt; i += WAVE)
@@ -997,7 +1023,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned char *>(a.in + tb), 0, (int)(lm & ~15u), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < SUBS; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, j * SUB + lane * 16, 0, 0);
+        for (int j = 0; j < SUBS; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, j * SUB + lane * 16, 0, LOAD_AUX);
         if (lane * 16 < a.halo) hw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, WTILE + lane * 16, 0, 0);
     };
     // this wave's tile of round rr; false: there is none (the input is used up) or the ring timed out.
@@ -1339,9 +1365,13 @@ __device__ __forceinline__ unsigned long long match_hash(unsigned long long pos,
 
 // Records are read through the tile index (the heap has gaps): tile t holds tix[t] >> 40 records from index
 // tix[t] & TIX_BASE_MASK on; records past the capacity of the array were never written.
-template <bool PACKED>
+template <int BYTES>
 __device__ __forceinline__ void heap_record(const void *rec, unsigned long long i, unsigned long long tile, unsigned &pos, unsigned &state) {
-    if (PACKED) {
+    if (BYTES == 2) {
+        const unsigned w = static_cast<const unsigned short *>(rec)[i];
+        pos = (unsigned)(tile * WTILE) + (w & 0xFFFu);
+        state = w >> 12;
+    } else if (BYTES == 4) {
         const unsigned w = static_cast<const unsigned *>(rec)[i];
         pos = (unsigned)(tile * WTILE) + (w & 0xFFFu);
         state = w >> 12;
@@ -1353,7 +1383,7 @@ __device__ __forceinline__ void heap_record(const void *rec, unsigned long long 
 }
 
 // Order-independent checksum of all records: one wave per tile at a time.
-template <bool PACKED>
+template <int BYTES>
 __global__ void pfac_checksum_kernel(const void *rec, const unsigned long long *tix, unsigned long long n_tiles,
                                      unsigned long long cap, unsigned long long base, const int *idmap, unsigned long long *out) {
     unsigned long long sum = 0;
@@ -1364,7 +1394,7 @@ __global__ void pfac_checksum_kernel(const void *rec, const unsigned long long *
         const unsigned cnt = (unsigned)(e >> TIX_CNT_SHIFT);
         for (unsigned i = (unsigned)lane; i < cnt && lo + i < cap; i += WAVE) {
             unsigned pos, st;
-            heap_record<PACKED>(rec, lo + i, t, pos, st);
+            heap_record<BYTES>(rec, lo + i, t, pos, st);
             sum += match_hash(base + pos, (unsigned)idmap[st]);
         }
     }
@@ -1401,7 +1431,7 @@ __global__ void pfac_scan_groups_kernel(unsigned long long *gsum, unsigned n_gro
     for (unsigned i = lo; i < hi; i++) { const unsigned long long v = gsum[i]; gsum[i] = acc; acc += v; }
 }
 // records [first, first + n) of the sorted sequence -> out[0, n)
-template <bool PACKED>
+template <int BYTES>
 __global__ void pfac_expand_kernel(const void *rec, const unsigned long long *tix, unsigned long long n_tiles,
                                    const unsigned long long *gpre, unsigned n_groups, unsigned long long cap,
                                    unsigned long long first, unsigned long long n, pfac_record *out) {
@@ -1423,7 +1453,7 @@ __global__ void pfac_expand_kernel(const void *rec, const unsigned long long *ti
             const unsigned long long k = toff + i;
             if (k < first || k >= end || tlo + i >= cap) continue;
             pfac_record o;
-            heap_record<PACKED>(rec, tlo + i, (unsigned long long)g * XGROUP + j, o.pos, o.state);
+            heap_record<BYTES>(rec, tlo + i, (unsigned long long)g * XGROUP + j, o.pos, o.state);
             out[k - first] = o;
         }
     }
@@ -1478,7 +1508,7 @@ struct Slot {
     uint64_t gsum_cap = 0;
     pfac_record *d_wide = nullptr;        // scratch of pfac_records_d2h: packed records expanded on the device
     uint64_t wide_cap = 0;
-    bool last_packed = false;             // record format of the slot's last scan
+    int last_rec_bytes = 4;               // record form of the slot's last scan (2, 4 or 8 bytes)
     const void *last_records = nullptr;   // ... and where it wrote
     unsigned *d_ctl = nullptr;            // TWO control headers (ticket counters, flags, heap cursor), used alternately:
     unsigned *d_ctlbuf[2] = {nullptr, nullptr};   // a scan zeroes the other one for the scan after it
@@ -1523,7 +1553,7 @@ struct pfac_ctx {
     int d1_rows = 0;
     int d1_n2 = 0;                        // > 0: dense rows are packed (fused tables), r[] of the depth-2 states follows them
     int grid_blocks = 0;
-    bool packed = true;                   // record format: 4-byte words + tile index (final states fit 20 bits), else 8-byte records
+    int rec_bytes = 4;                    // record form: 2 (<= 16 final states), 4 (<= 2^20), 8 bytes (pfac_record)
     // level-2 filter (ScanArgs::l2f_mode)
     unsigned char *d_bm2 = nullptr;       // 2-byte-prefix bitmap, 256 rows of 32 bytes
     int l2f_mode = 0, n_child = 0, bm2_rows = 0, sh_bm2 = 0, sec_filter = 0;
@@ -1729,8 +1759,11 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->root_mode = fan == 1 ? 1 : 0;
     ctx->root_byte = (unsigned)rb * 0x01010101u;
     ctx->root_state = s0_host[rb];
-    ctx->packed = ctx->num_final <= (1 << PACK_STATE_BITS) && !getenv("PFAC_WIDE");   // PFAC_WIDE: test knob, 8-byte records
-    ctx->stage_cap = ctx->packed ? stage_cap : 0u;
+    // records are as wide as the automaton needs: 12 position bits + the final state
+    ctx->rec_bytes = ctx->num_final <= 16 ? 2 : (ctx->num_final <= (1 << PACK_STATE_BITS) ? 4 : 8);
+    const int rb_knob = env_int("PFAC_REC_BYTES", getenv("PFAC_WIDE") ? 8 : 0);     // test knob: a WIDER form than needed
+    if ((rb_knob == 4 || rb_knob == 8) && rb_knob > ctx->rec_bytes) ctx->rec_bytes = rb_knob;
+    ctx->stage_cap = ctx->rec_bytes < 8 ? stage_cap : 0u;
     // dense-mode layout
     ctx->pw_bytes_d = (int)align_up((size_t)PW_FIXED_DENSE + ctx->halo, 16);
     int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
@@ -1983,7 +2016,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     const int lds_bytes = dense ? ctx->lds_bytes_d : ctx->lds_bytes;
     s.last_dense = dense;
     s.last_tiles = n_tiles;
-    s.last_packed = ctx->packed;
+    s.last_rec_bytes = ctx->rec_bytes;
     s.last_records = d_records;
     // The control header (ticket counters, flags, heap cursor) must start at zero.  The slot has two: every scan
     // zeroes, in its own prologue, the other one for the scan after it, so back-to-back scans need no memset.
@@ -2000,7 +2033,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.in = in; a.n_owned = n_owned; a.n_avail = n_avail;
         a.out = d_records; a.out_cap = capacity;
         a.tile_index = s.d_tile_index;
-        a.packed = ctx->packed ? 1u : 0u;
+        a.rec_bytes = (unsigned)ctx->rec_bytes;
         a.l2f_mode = ctx->l2f_mode; a.child0 = ctx->child0; a.child1 = ctx->child1; a.n_child = ctx->n_child;
         a.bm2 = ctx->d_bm2; a.bm2_rows = ctx->bm2_rows; a.sh_bm2 = ctx->sh_bm2;
         a.sec2 = ctx->d_bm2 + 256 * 32; a.sec_filter = ctx->sec_filter;
@@ -2121,24 +2154,19 @@ static int expand_records(pfac_ctx *ctx, Slot &s, const void *src, uint64_t firs
     hipLaunchKernelGGL(pfac_tix_group_sum_kernel, dim3(gblocks), dim3(256), 0, s.stream, s.d_tile_index,
                        (unsigned long long)s.last_tiles, s.d_gsum, n_groups);
     hipLaunchKernelGGL(pfac_scan_groups_kernel, dim3(1), dim3(1024), 0, s.stream, s.d_gsum, n_groups);
-    if (s.last_packed)
-        hipLaunchKernelGGL(pfac_expand_kernel<true>, dim3(gblocks), dim3(256), 0, s.stream, src, s.d_tile_index,
-                           (unsigned long long)s.last_tiles, s.d_gsum, n_groups, (unsigned long long)s.last_cap,
-                           (unsigned long long)first, (unsigned long long)n, d_out);
-    else
-        hipLaunchKernelGGL(pfac_expand_kernel<false>, dim3(gblocks), dim3(256), 0, s.stream, src, s.d_tile_index,
-                           (unsigned long long)s.last_tiles, s.d_gsum, n_groups, (unsigned long long)s.last_cap,
-                           (unsigned long long)first, (unsigned long long)n, d_out);
+    auto ek = s.last_rec_bytes == 2 ? pfac_expand_kernel<2> : (s.last_rec_bytes == 4 ? pfac_expand_kernel<4> : pfac_expand_kernel<8>);
+    hipLaunchKernelGGL(ek, dim3(gblocks), dim3(256), 0, s.stream, src, s.d_tile_index, (unsigned long long)s.last_tiles,
+                       s.d_gsum, n_groups, (unsigned long long)s.last_cap, (unsigned long long)first, (unsigned long long)n, d_out);
     HIP_TRY(ctx, hipGetLastError());
     return PFAC_OK;
 }
 
-int pfac_scan_format(pfac_ctx *ctx, int slot, int *packed, uint64_t *n_tiles, uint64_t *used) {
+int pfac_scan_format(pfac_ctx *ctx, int slot, int *record_bytes, uint64_t *n_tiles, uint64_t *used) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     if (!s.scanned) return fail(ctx, PFAC_E_STATE, "no scan yet");
-    if (packed) *packed = s.last_packed ? 1 : 0;
+    if (record_bytes) *record_bytes = s.last_rec_bytes;
     if (n_tiles) *n_tiles = s.last_tiles;
     if (used) *used = s.last_used;
     return PFAC_OK;
@@ -2187,17 +2215,17 @@ int pfac_records_d2h(pfac_ctx *ctx, int slot, const void *d_records, pfac_record
     return PFAC_OK;
 }
 
-int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, uint32_t *host_words, uint64_t n_words,
+int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, void *host_words, uint64_t n_words,
                             uint64_t *host_tile_index) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     const void *src = d_records ? d_records : s.d_records;
-    if (!s.scanned || !s.last_packed) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h_packed: the slot's last scan did not produce packed records");
+    if (!s.scanned || s.last_rec_bytes == 8) return fail(ctx, PFAC_E_STATE, "pfac_records_d2h_packed: the slot's last scan did not produce compact records");
     if (!src || (!host_words && n_words) || !host_tile_index) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: null buffer");
     if (n_words > s.last_cap) return fail(ctx, PFAC_E_ARG, "pfac_records_d2h_packed: more words than the record array holds");
     USE_DEVICE(ctx);
-    if (n_words) HIP_TRY(ctx, hipMemcpyAsync(host_words, src, n_words * 4, hipMemcpyDeviceToHost, s.stream));
+    if (n_words) HIP_TRY(ctx, hipMemcpyAsync(host_words, src, n_words * (uint64_t)s.last_rec_bytes, hipMemcpyDeviceToHost, s.stream));
     if (s.last_tiles) HIP_TRY(ctx, hipMemcpyAsync(host_tile_index, s.d_tile_index, s.last_tiles * 8, hipMemcpyDeviceToHost, s.stream));
     return PFAC_OK;
 }
@@ -2222,14 +2250,9 @@ int pfac_records_checksum(pfac_ctx *ctx, int slot, const void *d_records, uint64
     USE_DEVICE(ctx);
     HIP_TRY(ctx, hipMemsetAsync(s.d_sum, 0, 16, s.stream));
     if (n && s.last_tiles) {
-        if (s.last_packed)
-            hipLaunchKernelGGL(pfac_checksum_kernel<true>, dim3(1024), dim3(256), 0, s.stream, src, s.d_tile_index,
-                               (unsigned long long)s.last_tiles, (unsigned long long)s.last_cap, (unsigned long long)base,
-                               ctx->d_idmap, s.d_sum);
-        else
-            hipLaunchKernelGGL(pfac_checksum_kernel<false>, dim3(1024), dim3(256), 0, s.stream, src, s.d_tile_index,
-                               (unsigned long long)s.last_tiles, (unsigned long long)s.last_cap, (unsigned long long)base,
-                               ctx->d_idmap, s.d_sum);
+        auto ck = s.last_rec_bytes == 2 ? pfac_checksum_kernel<2> : (s.last_rec_bytes == 4 ? pfac_checksum_kernel<4> : pfac_checksum_kernel<8>);
+        hipLaunchKernelGGL(ck, dim3(1024), dim3(256), 0, s.stream, src, s.d_tile_index, (unsigned long long)s.last_tiles,
+                           (unsigned long long)s.last_cap, (unsigned long long)base, ctx->d_idmap, s.d_sum);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemcpyAsync(s.h_ctl + 8, s.d_sum, 8, hipMemcpyDeviceToHost, s.stream));

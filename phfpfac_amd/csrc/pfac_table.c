@@ -624,7 +624,8 @@ static inline char *put_uint(char *p, uint64_t v, int min_width) {
  * ordered tile index; tile_pre[t] = records of the tiles before t, tile_pre[n_tiles] = all). */
 typedef struct {
     const pfac_record *rec;
-    const uint32_t *words;
+    const void *words;              /* 16- or 32-bit words (word_bytes) */
+    int word_bytes;
     const uint64_t *tile_index;
     const uint64_t *tile_pre;
     uint64_t n_tiles;
@@ -650,7 +651,8 @@ static char *format_records(const rec_src *s, uint64_t k0, uint64_t k1, uint64_t
         uint32_t st;
         if (s->words) {
             while (k >= s->tile_pre[t + 1]) t++;
-            const uint32_t w = s->words[PFAC_TIX_FIRST(s->tile_index[t]) + (k - s->tile_pre[t])];
+            const uint64_t at = PFAC_TIX_FIRST(s->tile_index[t]) + (k - s->tile_pre[t]);
+            const uint32_t w = s->word_bytes == 2 ? ((const uint16_t *)s->words)[at] : ((const uint32_t *)s->words)[at];
             pos = base + t * PFAC_TILE_BYTES + PFAC_PACKED_POS(w);
             st = PFAC_PACKED_STATE(w);
         } else {
@@ -693,7 +695,7 @@ static int64_t emit_serial(FILE *f, const rec_src *s, uint64_t n, uint64_t base,
 
 int64_t pfac_emit_records(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap) {
     if (!file || (!rec && n)) return PFAC_E_ARG;
-    const rec_src s = {rec, NULL, NULL, NULL, 0};
+    const rec_src s = {rec, NULL, 0, NULL, NULL, 0};
     return emit_serial((FILE *)file, &s, n, base, idmap);
 }
 
@@ -831,13 +833,13 @@ static int64_t emit_mt(FILE *f, const rec_src *src, uint64_t n, uint64_t base, c
 int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uint64_t base, const int32_t *idmap,
                              int n_threads) {
     if (!file || (!rec && n)) return PFAC_E_ARG;
-    const rec_src s = {rec, NULL, NULL, NULL, 0};
+    const rec_src s = {rec, NULL, 0, NULL, NULL, 0};
     return emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
 }
 
-int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile_index, uint64_t n_tiles, uint64_t base,
-                         const int32_t *idmap, int n_threads) {
-    if (!file || (!tile_index && n_tiles)) return PFAC_E_ARG;
+int64_t pfac_emit_packed(void *file, const void *words, int record_bytes, const uint64_t *tile_index, uint64_t n_tiles,
+                         uint64_t base, const int32_t *idmap, int n_threads) {
+    if (!file || (!tile_index && n_tiles) || (record_bytes != 2 && record_bytes != 4)) return PFAC_E_ARG;
     uint64_t *pre = (uint64_t *)malloc((size_t)(n_tiles + 1) * sizeof(uint64_t));
     if (!pre) return PFAC_E_NOMEM;
     uint64_t n = 0;
@@ -845,7 +847,7 @@ int64_t pfac_emit_packed(void *file, const uint32_t *words, const uint64_t *tile
     pre[n_tiles] = n;
     int64_t rc = PFAC_E_ARG;
     if (words || !n) {
-        const rec_src s = {NULL, words, tile_index, pre, n_tiles};
+        const rec_src s = {NULL, words, record_bytes, tile_index, pre, n_tiles};
         rc = emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
     }
     free(pre);

@@ -147,12 +147,12 @@ class GpuMatcher:
             self.sync(slot)
         return out
 
-    def scan_format(self, slot: int = 0) -> Tuple[bool, int, int]:
-        """(packed, n_tiles, used) of the slot's last scan: packed = 4-byte words in the record heap, n_tiles = entries
-        of the tile index, used = heap records in use (gaps included)."""
-        pk, nt, used = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
-        self._check(self._L.pfac_scan_format(self._ctx, slot, C.byref(pk), C.byref(nt), C.byref(used)))
-        return bool(pk.value), nt.value, used.value
+    def scan_format(self, slot: int = 0) -> Tuple[int, int, int]:
+        """(record_bytes, n_tiles, used) of the slot's last scan: record_bytes = 2 or 4 (compact words in the record
+        heap) or 8 (pfac_record), n_tiles = entries of the tile index, used = heap records in use (gaps included)."""
+        rb, nt, used = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.pfac_scan_format(self._ctx, slot, C.byref(rb), C.byref(nt), C.byref(used)))
+        return rb.value, nt.value, used.value
 
     def capacity_hint(self, slot: int = 0) -> int:
         """A record capacity the slot's last scan fits (after an overflow)."""
@@ -166,9 +166,9 @@ class GpuMatcher:
         self._check(self._L.pfac_records_expand(self._ctx, slot, _ptr(d_records), int(first), int(n), _ptr(d_out)))
 
     def packed_to_host(self, slot: int = 0, d_records=None) -> Tuple[np.ndarray, np.ndarray]:
-        """The compact device form itself: (uint32 heap words [used], uint64 tile index [n_tiles])."""
-        _, nt, used = self.scan_format(slot)
-        words = np.empty(int(used), dtype=np.uint32)
+        """The compact device form itself: (uint16 or uint32 heap words [used], uint64 tile index [n_tiles])."""
+        rb, nt, used = self.scan_format(slot)
+        words = np.empty(int(used), dtype=np.uint16 if rb == 2 else np.uint32)
         tix = np.empty(max(nt, 1), dtype=np.uint64)
         self._check(self._L.pfac_records_d2h_packed(self._ctx, slot, _ptr(d_records), words.ctypes.data, int(used), tix.ctypes.data))
         self.sync(slot)

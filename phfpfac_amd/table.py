@@ -212,14 +212,16 @@ def emit_packed(path, words: np.ndarray, tile_index: np.ndarray, idmap, base: in
     libc.fopen.restype = C.c_void_p
     libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
     libc.fclose.argtypes = [C.c_void_p]
-    words = np.ascontiguousarray(words, dtype=np.uint32)
+    words = np.ascontiguousarray(words)
+    if words.dtype not in (np.uint16, np.uint32):
+        raise TypeError("compact records are uint16 or uint32 words")
     tix = np.ascontiguousarray(tile_index, dtype=np.uint64)
     idmap = None if idmap is None else np.ascontiguousarray(idmap, dtype=np.int32)
     f = libc.fopen(os.fsencode(path), b"wb")
     if not f:
         raise PfacError(-2, f"cannot open {path}")
     try:
-        n = L.pfac_emit_packed(f, words.ctypes.data, tix.ctypes.data, tix.size, int(base),
+        n = L.pfac_emit_packed(f, words.ctypes.data, int(words.dtype.itemsize), tix.ctypes.data, tix.size, int(base),
                                None if idmap is None else idmap.ctypes.data, int(threads))
     finally:
         libc.fclose(f)

@@ -105,6 +105,7 @@ def test_dictionary_dense_mode_kernels(width, env, resolve, monkeypatch):
                                  {"PFAC_FORCE_L2": "1", "PFAC_NO_FUSE": "1"}, {"PFAC_NWB": "5", "PFAC_DENSE": "1"},
                                  {"PFAC_NWB": "3"}, {"PFAC_NO_D1": "1"},
                                  {"PFAC_WIDE": "1"},                      # 8-byte records in the heap (automata beyond 2^20 final states)
+                                 {"PFAC_REC_BYTES": "4"},                 # 32-bit records where 16 bits would do
                                  {"PFAC_WIDE": "1", "PFAC_FORCE_L2": "1", "PFAC_DENSE": "1"},
                                  {"PFAC_L2F": "0"}, {"PFAC_L2F": "2"},    # level-2 filter off / lookup form where the SWAR form applies
                                  {"PFAC_L2F": "2", "PFAC_FORCE_L2": "1"}, {"PFAC_NO_SECF": "1", "PFAC_FORCE_L2": "1"}])
@@ -533,8 +534,8 @@ def test_rccl_path_single_rank(resolve):
             g.scan_async(hi - lo, end - lo, d_input=buf, d_records=rec_t, capacity=rec_t.numel())
             n, over = g.scan_finish(0)
             assert not over
-            packed, n_tiles, used = g.scan_format(0)                      # compact words in a heap + tile index
-            assert packed and n_tiles == -(-(hi - lo) // 4096) and n <= used <= rec_t.numel()
+            rec_bytes, n_tiles, used = g.scan_format(0)                   # compact words in a heap + tile index
+            assert rec_bytes == 4 and n_tiles == -(-(hi - lo) // 4096) and n <= used <= rec_t.numel()
             g.expand_records(n, wide_t, d_records=rec_t)                  # -> pfac_record, still on the device
             g.sync(0)
         counts = pdist.gather_counts(n, dev)
@@ -621,9 +622,9 @@ def test_compact_form_to_text(resolve, tmp_path):
     with GpuMatcher(0, 1) as g:
         g.load_table(table)
         rec = g.scan_bytes(data)
-        packed, n_tiles, used = g.scan_format(0)
+        rec_bytes, n_tiles, used = g.scan_format(0)
         words, tix = g.packed_to_host(0)
-    assert packed and n_tiles == -(-data.size // 4096) and words.size == used >= rec.size
+    assert rec_bytes == 4 and words.dtype == np.uint32 and n_tiles == -(-data.size // 4096) and words.size == used >= rec.size
     cnt = (tix >> np.uint64(40)).astype(np.int64)
     first = (tix & np.uint64((1 << 40) - 1)).astype(np.int64)
     assert int(cnt.sum()) == rec.size == c["lines"]
@@ -632,6 +633,24 @@ def test_compact_form_to_text(resolve, tmp_path):
     out = tmp_path / "packed.txt"
     for threads in (1, 5):
         assert emit_packed(str(out), words, tix, table.idmap, threads=threads) == c["bytes"]
+        assert hashlib.md5(out.read_bytes()).hexdigest() == c["md5"]
+    # an automaton with at most 16 final states gets 16-bit records (4 patterns here); PFAC_REC_BYTES=4 widens them
+    c = FP["cases"]["exp_x_1M_s1_w256"]
+    table = PfacTable.from_file(resolve(c["pattern"]), c["width"])
+    data = np.frombuffer(open(resolve(c["input"]), "rb").read()[:-1], dtype=np.uint8)
+    for knob, want_bytes, dt in ((None, 2, np.uint16), ("4", 4, np.uint32)):
+        if knob:
+            os.environ["PFAC_REC_BYTES"] = knob
+        try:
+            with GpuMatcher(0, 1) as g:
+                g.load_table(table)
+                rec = g.scan_bytes(data)
+                rec_bytes, _, used = g.scan_format(0)
+                words, tix = g.packed_to_host(0)
+        finally:
+            os.environ.pop("PFAC_REC_BYTES", None)
+        assert rec_bytes == want_bytes and words.dtype == dt and words.size == used and rec.size == c["lines"]
+        assert emit_packed(str(out), words, tix, table.idmap, threads=3) == c["bytes"]
         assert hashlib.md5(out.read_bytes()).hexdigest() == c["md5"]
 
 

@@ -273,6 +273,14 @@ def test_emit_from_record_heap_and_tile_index(tmp_path):
         nc = emit_packed(str(c_), words, tix, idmap, base=base, threads=6)
         assert na == nb == nc
         assert a.read_bytes() == b.read_bytes() == c_.read_bytes()
+    # the 16-bit form (automata with at most 16 final states): same tiles, states folded to 4 bits
+    rec16 = rec.copy()
+    rec16["state"] &= 15
+    words16 = (words & np.uint32(0xFFFF)).astype(np.uint16)
+    na = emit_records(str(a), rec16, idmap)
+    for threads in (1, 6):
+        assert emit_packed(str(b), words16, tix, idmap, threads=threads) == na
+        assert a.read_bytes() == b.read_bytes()
     # no tiles at all / only empty tiles
     assert emit_packed(str(b), np.zeros(1, np.uint32), np.zeros(0, np.uint64), idmap) == 0
     assert emit_packed(str(b), np.zeros(1, np.uint32), np.zeros(9, np.uint64), idmap) == 0
