@@ -1077,9 +1077,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #endif
         PFAC_STAMP(trace, 4);
         // ---- registers -> LDS (tile + halo), then start the loads of the tile LOAD_DEPTH rounds ahead right away
+#ifndef PFAC_ABL_NOLDSCOPY                     // ablation builds only: the tile never reaches LDS (wrong masks)
 #pragma unroll
         for (int j = 0; j < SUBS; j++) *reinterpret_cast<u32x4 *>(tile + j * SUB + lane * 16) = w[j];
         if (lane * 16 < a.halo) *reinterpret_cast<u32x4 *>(tile + WTILE + lane * 16) = hw;
+#else
+        asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(hw));
+#endif
         if (lim & 15u) {                       // ragged end of the input (last tile only): patch the tail bytes
             wave_lds_sync();
             if (lane < (int)(lim & 15u)) tile[(lim & ~15u) + lane] = a.in[tile_base + (lim & ~15u) + lane];
@@ -1098,7 +1102,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             const unsigned off = j * MSUB + lane * MLANE;
             const u32x4 lo16 = *reinterpret_cast<const u32x4 *>(tile + off);
             const u32x4 hi16 = *reinterpret_cast<const u32x4 *>(tile + off + 16);
+#ifdef PFAC_ABL_NOROOT                         // ablation builds only: no root test (nothing survives)
+            const unsigned rlo = (lo16[0] == 0x12345678u), rhi = (hi16[0] == 0x12345678u);
+#else
             const unsigned rlo = root_mask<ROOT>(lo16, ftab, a.root_byte), rhi = root_mask<ROOT>(hi16, ftab, a.root_byte);
+#endif
             const unsigned raw = (rlo & 0xFFFFu) | (rhi << 16);
             unsigned m1 = raw;
             if (tile_base + WTILE > a.n_owned) {   // last tile only: offsets at or past n_owned start no walk
