@@ -81,7 +81,7 @@ HIP_SYMBOLS = (
     "pfac_table_upload_device", "pfac_host_alloc", "pfac_host_free", "pfac_slot_reserve", "pfac_slot_input",
     "pfac_slot_records", "pfac_slot_stream", "pfac_slot_set_stream", "pfac_slot_h2d", "pfac_scan_async",
     "pfac_scan_finish", "pfac_scan_elapsed_ms", "pfac_records_d2h", "pfac_slot_sync", "pfac_records_checksum",
-    "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_trace_table_compat", "pfac_scan_format",
+    "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_scan_staging", "pfac_trace_table_compat", "pfac_scan_format",
     "pfac_records_expand", "pfac_records_d2h_packed", "pfac_scan_capacity_hint",
 )
 
@@ -184,6 +184,7 @@ def hip_lib() -> C.CDLL:
         L.pfac_fill_tiled.argtypes = [vp, i, vp, u64, vp, C.c_uint32, u64]
         L.pfac_fill_random.argtypes = [vp, i, vp, u64, u64]
         L.pfac_scan_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+        L.pfac_scan_staging.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_uint32)]
         L.pfac_trace_table_compat.argtypes = [C.POINTER(CThreadData), i]
         _hip = L
     return _hip

@@ -103,18 +103,19 @@ constexpr bool MASK_GATHERS = PFAC_MASK_GATHERS != 0;   // fused walks: exec-mas
 #endif
 constexpr int LOAD_AUX = PFAC_LOAD_AUX;    // cache policy of the tile loads (0 default, 2 = nt: the input is read once)
 constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
-// per-wave LDS: tile bytes + halo | survivor FIFO | two record staging buffers
-#ifndef PFAC_NBUF
-#define PFAC_NBUF 2
-#endif
-constexpr int NBUF = PFAC_NBUF;            // staging buffers: a tile's records are emitted NBUF-1 rounds later
-constexpr int LAG = NBUF - 1;
-static_assert(NBUF == 2 || NBUF == 3, "one or two rounds of emission lag");
-constexpr int PW_FIXED = WTILE + QCAP * 2 + NBUF * CAPW * 4;
+// per-wave LDS: tile bytes + halo | survivor FIFO | nbuf record staging buffers.  A tile's records leave nbuf - 1 rounds
+// after it was scanned (its record base needs every count of its round).  nbuf = 3 where LDS allows: the stores then
+// go out at the TOP of a round, right behind the next tile's loads, and have the whole round to complete -- with two
+// buffers they can only go at the END (the base of the previous round is not in earlier), and since loads and stores
+// retire through one in-order counter (vmcnt) the next round's wait for its tile also waits for their write
+// acknowledgements (measured: 6 % of the headline kernel).
+constexpr int NBUF_MAX = 3;
+constexpr int CAPW3_MIN = 256;             // the three-buffer layout needs room for this many records per buffer
+constexpr int PW_FIXED_1BUF = WTILE + QCAP * 2;              // + nbuf * stage_cap * 4
 // Dense mode (most tiles hold more matches than CAPW, e.g. a dictionary on text): ONE big staging buffer per
 // wave and synchronous emission -- fewer waves fit, but a tile is walked once instead of twice.
 constexpr int CAPW_DENSE = 2048;
-constexpr int PW_FIXED_DENSE = WTILE + QCAP * 2 + CAPW_DENSE * 4;
+constexpr int PW_FIXED_DENSE = PW_FIXED_1BUF + CAPW_DENSE * 4;
 
 // Batch tickets: one address sustains ~85 M atomics/s, and at 4 TB/s with 60 KiB per ticket the workgroups ask for
 // 65 M/s -- the single counter was the floor of the whole kernel (3.9 us per round with the scan compiled out).  So
@@ -129,7 +130,7 @@ constexpr unsigned TICKET_WAYS = PFAC_TICKET_WAYS;
 constexpr unsigned CTL_WORDS = 64u * (TICKET_WAYS + 1);   // control header in 32-bit words: one 256-byte line per ticket counter + the cursor's
 constexpr unsigned SPIN_MAX = 1u << 22;    // bounded spins (default; PFAC_SPIN_MAX): ~0.5 s of LDS polls, seconds of global polls
 // words of the control header (first ticket line) the kernel reports through: device memory, ordinary device atomics
-constexpr unsigned CTL_ERR = 32, CTL_OVF = 33, CTL_DONE = 34, CTL_TOTAL = 36 /* u64: matches */;
+constexpr unsigned CTL_ERR = 32, CTL_OVF = 33, CTL_DONE = 34, CTL_OVF2 = 35, CTL_TOTAL = 36 /* u64: matches */;
 constexpr unsigned CTL_CURSOR = 64u * TICKET_WAYS;     // u64: first free record of the heap (on a line of its own)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -167,8 +168,9 @@ struct ScanArgs {
     const unsigned char *sec2;            // [256]: 1 where the byte is the second byte of some pattern (column OR of bm2)
     int sec_filter;                       // ROOT == 0, mode 2: pre-filter the lookups with sec2 (no 1-byte patterns)
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
-    unsigned nbuf;                        // staging buffers per wave: NBUF = emit NBUF-1 rounds late, 1 = emit at once (dense mode)
-    unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation)
+    unsigned nbuf;                        // staging buffers per wave: 3 / 2 = emit two / one round(s) later, 1 = emit at once (dense mode)
+    unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation) ...
+    unsigned small_cap;                   // ... and than this (the three-buffer capacity) in res[6]
     unsigned n_tiles;
     unsigned spin_max;             // bound of every spin loop
     unsigned fault;                // test knob (PFAC_FAULT): bit 0 = workgroup 1 never publishes the record bases of its second round
@@ -243,6 +245,7 @@ constexpr int H_CNT = 48;                  // 16 words per round: match count of
 constexpr int H_WBASE = H_CNT + RING * 16; // 32 words per round: {lo, hi} first record index of each compute wave
 constexpr int H_OVF = H_WBASE + RING * 32;  // tiles of this workgroup with more matches than sparse_cap
 constexpr int H_EXIT = H_OVF + 1;          // waves of this workgroup that have left the kernel
+constexpr int H_OVF2 = H_OVF + 2;          // tiles of this workgroup with more matches than small_cap
 constexpr int H_WORDS = H_OVF + 8;
 
 // Error channel: flags are OR-ed into the control header in DEVICE memory (ordinary device atomics; the last
@@ -661,6 +664,9 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             if (totals[j] == 0) continue;
             const unsigned lpos = j * MSUB + lane * MLANE;
             unsigned o = (j ? totals[0] : 0u) + incls[j] - cnts[j];
+#ifdef PFAC_ABL_NOSTAGE                        // ablation builds only: counted, never staged (stale records)
+            if (true) continue;
+#endif
             for (unsigned m = keep[j]; m; m &= m - 1) {
                 const unsigned pos = lpos + (__ffs(m) - 1);
                 if (DIRECT) put_record(a, wrun + o, pos, (unsigned)tile_base + pos, st);
@@ -737,6 +743,9 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
 // records (16 bytes) per lane per store, aligned to the record array.
 __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base, int lane) {
     if (cnt == 0) return;
+#ifdef PFAC_ABL_NOEMIT                         // ablation builds only: records never leave LDS
+    return;
+#endif
     if (a.rec_bytes == 2) {
         // automata with at most 16 final states: the record is the low half of the staged word; eight per 16-byte store
         unsigned short *out = static_cast<unsigned short *>(a.out);
@@ -828,7 +837,7 @@ __device__ __forceinline__ unsigned eq_mask32(const u32x4 lo16, const u32x4 hi16
 // emit round r-2]  and meet the coordinator only through the LDS rings above.
 constexpr int MAX_WAVES_NW4 = 10;          // four walks per lane need registers: at most 10 waves per workgroup (dense mode has 9-10)
 
-template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW>
+template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB>
 __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem, const ErrCh &err) {
     unsigned *hdr = reinterpret_cast<unsigned *>(smem + SH_HDR);
     int *s0 = reinterpret_cast<int *>(smem + SH_S0);
@@ -1002,6 +1011,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             if (local_total) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.ctl + CTL_TOTAL), local_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned ovf = lds_load(&hdr[H_OVF]);
             if (ovf) __hip_atomic_fetch_add(&a.ctl[CTL_OVF], ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned ovf2 = lds_load(&hdr[H_OVF2]);
+            if (ovf2) __hip_atomic_fetch_add(&a.ctl[CTL_OVF2], ovf2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -1059,10 +1070,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     }
 
     // pend_have[k]: the tile scanned k+1 rounds ago still sits in its staging buffer (pend_cnt[k] records)
-    bool pend_have[LAG];
-    unsigned pend_cnt[LAG], buf = 0;           // buf: staging buffer of the current round, (r % NBUF)
+    // NB == 3: the three-buffer kernels (a.nbuf == 3); NB == 2: two buffers, or one (dense mode)
+    constexpr int LAG_MAX = NB - 1;
+    const unsigned nbuf = NB == 3 ? 3u : a.nbuf;
+    const unsigned lag = NB == 3 ? 2u : a.nbuf - 1u;   // rounds between a tile's scan and its emission (0: dense mode)
+    bool pend_have[LAG_MAX];
+    unsigned pend_cnt[LAG_MAX], buf = 0;       // buf: staging buffer of the current round, (r % nbuf)
 #pragma unroll
-    for (int k = 0; k < LAG; k++) { pend_have[k] = false; pend_cnt[k] = 0; }
+    for (int k = 0; k < LAG_MAX; k++) { pend_have[k] = false; pend_cnt[k] = 0; }
 
     // One round: w / hw hold this round's tile; they are refilled with the tile LOAD_DEPTH rounds ahead as soon as
     // their bytes sit in LDS.  Returns false after the wave's last tile.
@@ -1093,6 +1108,18 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         unsigned long long t_far = 0;
         const bool more_far = (LOAD_DEPTH == 1 || have_n1) && probe(r + LOAD_DEPTH, t_far);
         if (more_far) issue_loads(t_far, w, hw);
+        // ---- emit the tile of `lag` rounds ago: its bases came when that round's last count was in (a tile without
+        // records has nothing to wait for: the coordinator stores the tile index).  Its buffer is the one after the
+        // current round's, cyclically.
+        auto emit_pending = [&](bool have, unsigned n_rec) {
+            if (have && n_rec != 0) {
+                unsigned long long base = 0;
+                const bool okb = record_base(r - lag, base);
+                PFAC_STAMP(trace, 9);
+                if (okb) copy_out(a, stage0 + (buf + 1u == nbuf ? 0u : buf + 1u) * a.stage_cap, n_rec, base, lane);
+            }
+        };
+        if (NB == 3) emit_pending(pend_have[LAG_MAX - 1], pend_cnt[LAG_MAX - 1]);      // stores right behind the loads
 
         // ---- root test -> 32-bit survivor mask per lane per half-tile; level-2 filter -> which of them are kept
         // (yield a record or need a walk) and which of those are deep (need the walk)
@@ -1190,14 +1217,17 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         if (a.dbg && blockIdx.x < 8 && r < 64 && lane == 0) tr[16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
         const bool overflow = cnt > a.stage_cap;
-        const bool now = overflow || a.nbuf == 1;          // this tile is emitted right away (needs its base at once)
+        const bool now = overflow || nbuf == 1;          // this tile is emitted right away (needs its base at once)
         unsigned arrival = 0;
 #ifdef PFAC_ABL_NOCOORD
         if (false)
 #endif
         if (lane == 0) {
             hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
-            if (cnt > a.sparse_cap) atomicAdd(&hdr[H_OVF], 1u);
+            if (cnt > a.small_cap) {
+                atomicAdd(&hdr[H_OVF2], 1u);
+                if (cnt > a.sparse_cap) atomicAdd(&hdr[H_OVF], 1u);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             arrival = atomicAdd(&hdr[H_ARRIVED + (r & 7)], 1u);
         }
@@ -1218,19 +1248,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                     copy_out(a, stage, (unsigned)cnt, base, lane);   // dense mode: staged, emitted at once
             }
         }
-        // ---- emit the tile of LAG rounds ago: its bases came when that round's last count was in (a tile without
-        // records has nothing to wait for: the coordinator stores the tile index)
-        if (pend_have[LAG - 1] && pend_cnt[LAG - 1] != 0) {
-            unsigned long long base = 0;
-            const bool okb = record_base(r - LAG, base);
-            PFAC_STAMP(trace, 9);
-            if (okb) copy_out(a, stage0 + ((buf + 1) % NBUF) * a.stage_cap, pend_cnt[LAG - 1], base, lane);
-        }
+        if (NB == 2) emit_pending(pend_have[0], pend_cnt[0]);
         PFAC_STAMP(trace, 8);
-#pragma unroll
-        for (int k = LAG - 1; k > 0; k--) { pend_have[k] = pend_have[k - 1]; pend_cnt[k] = pend_cnt[k - 1]; }
+        if (NB == 3) { pend_have[LAG_MAX - 1] = pend_have[0]; pend_cnt[LAG_MAX - 1] = pend_cnt[0]; }
         pend_have[0] = !now; pend_cnt[0] = (unsigned)cnt;
-        buf = a.nbuf == 1 ? 0u : (buf + 1) % NBUF;
+        buf = buf + 1u >= nbuf ? 0u : buf + 1u;
         if (LOAD_DEPTH == 1) {
             if (!more_far) return false;
             t = t_far;
@@ -1247,24 +1269,25 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         if (!round_body(wA, hA)) break;
         if (LOAD_DEPTH == 2 && !round_body(wB, hB)) break;
     }
-    // drain: the tiles of the last LAG rounds (pend_have[k]: round r - k, staged in buffer (r - k) % NBUF)
+    // drain: the tiles of the last `lag` rounds (pend_have[k]: round r - k, staged in buffer (r - k) % nbuf)
 #pragma unroll
-    for (int k = LAG - 1; k >= 0; k--) {
-        if (pend_have[k] && pend_cnt[k] != 0) {
+    for (int k = LAG_MAX - 1; k >= 0; k--) {
+        if ((unsigned)k < lag && pend_have[k] && pend_cnt[k] != 0) {
             unsigned long long base = 0;
             if (record_base(r - (unsigned)k, base))
-                copy_out(a, stage0 + ((buf + NBUF - 1 - k) % NBUF) * a.stage_cap, pend_cnt[k], base, lane);
+                copy_out(a, stage0 + ((buf + nbuf - 1u - (unsigned)k) % nbuf) * a.stage_cap, pend_cnt[k], base, lane);
         }
     }
 }
 
-template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW>
+template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB = 2>
 __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLOCK)) void pfac_scan_kernel(ScanArgs a) {
+    static_assert(NB == 2 || (NB == 3 && TLDS), "three staging buffers: the kernels with their tables in LDS (the others have no LDS to spare)");
     static_assert(!(TLDS && FUSED), "the fused table is for tables gathered through L2");
     static_assert(NW == (TLDS ? 1 : 2) || (FUSED && (NW == 3 || NW == 4)), "walks per lane: 1 (LDS tables), 2 (L2 tables), 3 (L2, fused), 4 (L2, fused, dense matches)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ErrCh err = {&a.ctl[CTL_ERR], a.spin_max};
-    scan_body<TLDS, W8, ROOT, FUSED, NW>(a, smem, err);
+    scan_body<TLDS, W8, ROOT, FUSED, NW, NB>(a, smem, err);
     // ---- leaving: the last wave of the workgroup counts the workgroup out; the last workgroup of the grid copies
     // the error flags and the dense-tile count from the control header (device memory) to the host-visible result
     // words with plain stores.  Every wave comes through here, whichever way it left the loop.
@@ -1281,6 +1304,7 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
                 a.res[2] = __hip_atomic_load(&a.ctl[CTL_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a.res[3] = __hip_atomic_load(&a.ctl[CTL_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a.res[4] = (unsigned)cur; a.res[5] = (unsigned)(cur >> 32);
+                a.res[6] = __hip_atomic_load(&a.ctl[CTL_OVF2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1534,6 +1558,11 @@ struct Slot {
 
 }  // namespace
 
+struct StageLayout {                      // per-wave LDS of one staging mode
+    int nbuf = 2, pw_bytes = 0, waves_per_block = 0, lds_bytes = 0;
+    unsigned stage_cap = 0;               // records per buffer (0: final states do not fit the packed word)
+};
+
 struct pfac_ctx {
     int device = 0;
     int n_cu = 0;
@@ -1549,9 +1578,13 @@ struct pfac_ctx {
     int variant = 1;
     const void *kernel = nullptr;
     const void *kernel_d = nullptr;       // the kernel dense mode launches (four walks per lane on fused L2 tables)
-    int lds_bytes = 0, shared_bytes = 0, pw_bytes = 0, halo = 0, waves_per_block = 0, root_mode = 0;
-    unsigned root_byte = 0, stage_cap = 0;
+    const void *kernel3 = nullptr;        // the three-staging-buffer twin of `kernel` (tables in LDS only), else null
+    int shared_bytes = 0, halo = 0, root_mode = 0;
+    unsigned root_byte = 0;
     int root_state = -1;
+    StageLayout lay[2];                   // sparse staging: [0] two buffers (emission lags one round), [1] three (two rounds)
+    bool lag2_ok = false, lag2 = false, lag_forced = false;   // three-buffer layout usable / in use / pinned (PFAC_LAG)
+    const StageLayout &sparse() const { return lay[lag2 ? 1 : 0]; }
     // the dense-mode twin of {pw_bytes, waves_per_block, lds_bytes, stage_cap}: one big staging buffer per wave
     int pw_bytes_d = 0, waves_per_block_d = 0, lds_bytes_d = 0;
     unsigned stage_cap_d = 0;
@@ -1644,6 +1677,12 @@ int ensure_tiles(pfac_ctx *ctx, Slot &s, uint64_t n_entries) {
 int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v && *v ? atoi(v) : dflt;
+}
+
+static int max_lds(const pfac_ctx *ctx) {
+    int v = ctx->lds_bytes_d;
+    for (const StageLayout &L : ctx->lay) v = L.lds_bytes > v ? L.lds_bytes : v;
+    return v;
 }
 
 int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
@@ -1744,24 +1783,38 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->fault = (unsigned)env_int("PFAC_FAULT", 0);
     ctx->ticket_ways_knob = (unsigned)env_int("PFAC_TICKET_WAYS", 0);
     ctx->trace_file = getenv("PFAC_TRACE") ? getenv("PFAC_TRACE") : "";
-    ctx->pw_bytes = (int)align_up((size_t)PW_FIXED + ctx->halo, 16);
-    int nwb = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes + 1;     // compute waves + the coordinator (no LDS region)
-    if (nwb > MAX_WAVES_PER_BLOCK) nwb = MAX_WAVES_PER_BLOCK;
-    if (getenv("PFAC_NWB") && atoi(getenv("PFAC_NWB")) > 0 && atoi(getenv("PFAC_NWB")) < nwb) nwb = atoi(getenv("PFAC_NWB"));
-    if (nwb < 2) return fail(ctx, PFAC_E_INTERNAL, "LDS budget cannot hold one compute wave");
-    ctx->waves_per_block = nwb;
-    // LDS that no further wave fits into goes to the staging buffers: a tile may then hold more records (up to 1024
-    // per 4 KiB) before it has to be walked a second time
-    unsigned stage_cap = (unsigned)CAPW;
-    if (!getenv("PFAC_NWB")) {
-        const int spare = (LDS_TOTAL - ctx->shared_bytes) / (nwb - 1) - ctx->pw_bytes;      // bytes per compute wave
-        const int extra = spare > 0 ? (spare / (NBUF * 4)) & ~15 : 0;                       // records per staging buffer
-        stage_cap = (unsigned)(CAPW + extra) > 1024u ? 1024u : (unsigned)(CAPW + extra);
-        ctx->pw_bytes += (int)(stage_cap - CAPW) * NBUF * 4;
+    // The two-buffer layout fixes the number of waves; LDS that no further wave fits into goes to the staging buffers
+    // (up to 1024 records per 4 KiB tile before it has to be walked a second time).  The three-buffer layout (emission
+    // at the top of the round, see NBUF_MAX) is used when it keeps that many waves with room for >= CAPW3_MIN records.
+    const int nwb_knob = env_int("PFAC_NWB", 0);
+    for (int nb = 2; nb <= NBUF_MAX; nb++) {
+        StageLayout &L = ctx->lay[nb - 2];
+        L.nbuf = nb;
+        L.pw_bytes = (int)align_up((size_t)PW_FIXED_1BUF + (size_t)nb * CAPW * 4 + ctx->halo, 16);
+        int nwb = (LDS_TOTAL - ctx->shared_bytes) / L.pw_bytes + 1;     // compute waves + the coordinator (no LDS region)
+        if (nb == 3) {                                                  // as many waves as with two buffers, smaller buffers if need be
+            nwb = ctx->lay[0].waves_per_block;
+            L.pw_bytes = (int)align_up((size_t)PW_FIXED_1BUF + ctx->halo, 16);
+        }
+        if (nwb > MAX_WAVES_PER_BLOCK) nwb = MAX_WAVES_PER_BLOCK;
+        if (nwb_knob > 0 && nwb_knob < nwb) nwb = nwb_knob;
+        if (nwb < 2) return fail(ctx, PFAC_E_INTERNAL, "LDS budget cannot hold one compute wave");
+        L.waves_per_block = nwb;
+        const int base_cap = nb == 3 ? 0 : CAPW;
+        const int spare = (LDS_TOTAL - ctx->shared_bytes) / (nwb - 1) - L.pw_bytes;         // bytes per compute wave
+        const int extra = spare > 0 ? (spare / (nb * 4)) & ~15 : 0;                         // records per staging buffer
+        unsigned cap = (unsigned)(base_cap + ((nwb_knob && nb == 2) ? 0 : extra));
+        if (cap > 1024u) cap = 1024u;
+        L.pw_bytes += (int)(cap - base_cap) * nb * 4;
+        L.stage_cap = cap;
+        L.lds_bytes = ctx->shared_bytes + (nwb - 1) * L.pw_bytes;
+        // one workgroup per CU: ask for more than half of the LDS so two never share a CU while another idles
+        if (L.lds_bytes < LDS_TOTAL / 2 + 256) L.lds_bytes = LDS_TOTAL / 2 + 256;
     }
-    ctx->lds_bytes = ctx->shared_bytes + (nwb - 1) * ctx->pw_bytes;
-    // one workgroup per CU: ask for more than half of the LDS so two never share a CU while another idles
-    if (ctx->lds_bytes < LDS_TOTAL / 2 + 256) ctx->lds_bytes = LDS_TOTAL / 2 + 256;
+    const int lag_knob = env_int("PFAC_LAG", 0);          // 1 / 2: pin the emission lag (tests, A/B runs)
+    ctx->lag2_ok = ctx->lay[1].stage_cap >= (unsigned)CAPW3_MIN && lag_knob != 1;
+    ctx->lag2 = ctx->lag2_ok;
+    ctx->lag_forced = lag_knob == 1 || lag_knob == 2;
     ctx->grid_blocks = ctx->n_cu;
     // root fan-out 1 -> exact SWAR root test (ROOT = 1), else LDS flag tables (ROOT = 0)
     ctx->root_mode = fan == 1 ? 1 : 0;
@@ -1771,7 +1824,10 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->rec_bytes = ctx->num_final <= 16 ? 2 : (ctx->num_final <= (1 << PACK_STATE_BITS) ? 4 : 8);
     const int rb_knob = env_int("PFAC_REC_BYTES", getenv("PFAC_WIDE") ? 8 : 0);     // test knob: a WIDER form than needed
     if ((rb_knob == 4 || rb_knob == 8) && rb_knob > ctx->rec_bytes) ctx->rec_bytes = rb_knob;
-    ctx->stage_cap = ctx->rec_bytes < 8 ? stage_cap : 0u;
+    if (ctx->rec_bytes == 8) {                              // nothing is staged: every tile is written as it is walked
+        ctx->lay[0].stage_cap = ctx->lay[1].stage_cap = 0u;
+        ctx->lag2_ok = ctx->lag2 = false;
+    }
     // dense-mode layout
     ctx->pw_bytes_d = (int)align_up((size_t)PW_FIXED_DENSE + ctx->halo, 16);
     int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
@@ -1779,7 +1835,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->waves_per_block_d = nwd;
     ctx->lds_bytes_d = ctx->shared_bytes + (nwd - 1) * ctx->pw_bytes_d;
     if (ctx->lds_bytes_d < LDS_TOTAL / 2 + 256) ctx->lds_bytes_d = LDS_TOTAL / 2 + 256;
-    ctx->stage_cap_d = (nwd >= 4 && ctx->stage_cap) ? (unsigned)CAPW_DENSE : 0u;   // 0: dense mode unavailable
+    ctx->stage_cap_d = (nwd >= 4 && ctx->lay[0].stage_cap) ? (unsigned)CAPW_DENSE : 0u;   // 0: dense mode unavailable
     ctx->dense_forced = getenv("PFAC_DENSE") ? atoi(getenv("PFAC_DENSE")) : -1;
     ctx->dense = ctx->dense_forced == 1 && ctx->stage_cap_d;
     const bool w8 = ctx->width_bit == 8;
@@ -1805,6 +1861,16 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->kernel = k[ctx->variant == 0 ? 1 : (fused ? 2 : 0)][w8 ? 1 : 0][ctx->root_mode];
     // dense mode on fused L2 tables: four walks per lane (needs <= MAX_WAVES_NW4 waves per workgroup)
     ctx->kernel_d = ctx->kernel;
+    ctx->kernel3 = nullptr;
+    if (ctx->variant == 0) {
+        const void *k3[2][2] = {
+            {(const void *)pfac_scan_kernel<true, false, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, false, 1, false, 1, 3>},
+            {(const void *)pfac_scan_kernel<true, true, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, true, 1, false, 1, 3>}};
+        ctx->kernel3 = k3[w8 ? 1 : 0][ctx->root_mode];
+        HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
+    } else {
+        ctx->lag2_ok = ctx->lag2 = false;
+    }
     if (fused && !getenv("PFAC_NO_NW4")) {
         ctx->kernel_d = k[3][w8 ? 1 : 0][ctx->root_mode];
         if (ctx->waves_per_block_d > MAX_WAVES_NW4) {
@@ -1812,11 +1878,9 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
             ctx->lds_bytes_d = ctx->shared_bytes + (MAX_WAVES_NW4 - 1) * ctx->pw_bytes_d;
             if (ctx->lds_bytes_d < LDS_TOTAL / 2 + 256) ctx->lds_bytes_d = LDS_TOTAL / 2 + 256;
         }
-        HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel_d, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         ctx->lds_bytes > ctx->lds_bytes_d ? ctx->lds_bytes : ctx->lds_bytes_d));
+        HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel_d, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
     }
-    HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     ctx->lds_bytes > ctx->lds_bytes_d ? ctx->lds_bytes : ctx->lds_bytes_d));
+    HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
     return PFAC_OK;
 }
 
@@ -2017,11 +2081,12 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     s.last_cap = capacity;
     s.scanned = true;
     s.pending = true;
-    for (int i = 0; i < 6; i++) s.h_ctl[i] = 0;        // result words (the kernel writes them through the host mapping)
+    for (int i = 0; i < 7; i++) s.h_ctl[i] = 0;        // result words (the kernel writes them through the host mapping)
     // staging mode of this launch (see pfac_scan_finish for the adaptation)
     const bool dense = ctx->dense && ctx->stage_cap_d;
-    const int wpb = dense ? ctx->waves_per_block_d : ctx->waves_per_block;
-    const int lds_bytes = dense ? ctx->lds_bytes_d : ctx->lds_bytes;
+    const StageLayout &L = ctx->sparse();
+    const int wpb = dense ? ctx->waves_per_block_d : L.waves_per_block;
+    const int lds_bytes = dense ? ctx->lds_bytes_d : L.lds_bytes;
     s.last_dense = dense;
     s.last_tiles = n_tiles;
     s.last_rec_bytes = ctx->rec_bytes;
@@ -2050,7 +2115,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.r_words = ctx->max_row; a.t_entries = ctx->ht_size;
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
         a.halo = ctx->halo;
-        a.shared_bytes = ctx->shared_bytes; a.pw_bytes = dense ? ctx->pw_bytes_d : ctx->pw_bytes;
+        a.shared_bytes = ctx->shared_bytes; a.pw_bytes = dense ? ctx->pw_bytes_d : L.pw_bytes;
         a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows;
         a.d1_n2 = ctx->d1_n2;
         a.d1r2 = ctx->d1_n2 ? reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ctx->d_d1) +
@@ -2059,9 +2124,10 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;
         a.root_state = ctx->root_state;
-        a.stage_cap = dense ? ctx->stage_cap_d : ctx->stage_cap;
-        a.nbuf = dense ? 1u : (unsigned)NBUF;
-        a.sparse_cap = ctx->stage_cap;
+        a.stage_cap = dense ? ctx->stage_cap_d : L.stage_cap;
+        a.nbuf = dense ? 1u : (unsigned)L.nbuf;
+        a.sparse_cap = ctx->lay[0].stage_cap;
+        a.small_cap = ctx->lag2_ok ? ctx->lay[1].stage_cap : ctx->lay[0].stage_cap;
         a.n_tiles = (unsigned)n_tiles;
         a.ctl = cur;
         a.zero_next = reinterpret_cast<uint4 *>(nxt);
@@ -2086,7 +2152,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         if (chunk > (1u << 22)) chunk = 1u << 22;
         a.chunk = chunk >= 1024 ? (unsigned)chunk : 0u;
         void *kargs[] = {&a};
-        HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : ctx->kernel, dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
+        HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : (ctx->lag2 ? ctx->kernel3 : ctx->kernel), dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
         s.clean[s.flip] = false;               // used by this scan
         s.clean[1 - s.flip] = true;            // zeroed by this scan
         s.flip = 1 - s.flip;
@@ -2123,12 +2189,19 @@ int pfac_scan_finish(pfac_ctx *ctx, int slot, uint64_t *n_matches) {
                                           ": 4 arrivals, 8 record base, 16 batch ring)");
     }
     // Staging mode for the NEXT scans of this context: when more than a quarter of the tiles held more matches
-    // than the small (three-buffer) staging area takes, go dense (one big buffer, emitted at once, no second
-    // walk); go back when fewer than 1/16 do.  PFAC_DENSE=0/1 pins the mode.
+    // than the two-buffer staging area takes, go dense (one big buffer, emitted at once, no second walk); go back
+    // when fewer than 1/16 do.  PFAC_DENSE=0/1 pins the mode.  Likewise between the three- and the two-buffer layout,
+    // on the tiles above the (smaller) three-buffer capacity: 1/16 of the tiles walked twice cost what the earlier
+    // emission gains.  PFAC_LAG=1/2 pins that.
     if (ctx->dense_forced < 0 && ctx->stage_cap_d && s.last_tiles >= 64) {
         const uint64_t ovf = s.h_ctl[3];
         if (!ctx->dense && ovf * 4 > s.last_tiles) ctx->dense = true;
         else if (ctx->dense && ovf * 16 < s.last_tiles) ctx->dense = false;
+    }
+    if (ctx->lag2_ok && !ctx->lag_forced && s.last_tiles >= 64) {
+        const uint64_t ovf2 = s.h_ctl[6];
+        if (ctx->lag2 && ovf2 * 16 > s.last_tiles) ctx->lag2 = false;
+        else if (!ctx->lag2 && ovf2 * 64 < s.last_tiles) ctx->lag2 = true;
     }
     if (s.last_used > s.last_cap)
         return fail(ctx, PFAC_E_OVERFLOW, "record array too small: " + std::to_string(total) + " matches need " +
@@ -2310,7 +2383,16 @@ int pfac_scan_info(pfac_ctx *ctx, int *variant, int *tile_bytes, int *grid_block
     if (variant) *variant = ctx->variant;
     if (tile_bytes) *tile_bytes = WTILE;
     if (grid_blocks) *grid_blocks = ctx->grid_blocks;
-    if (lds_bytes) *lds_bytes = (ctx->dense && ctx->stage_cap_d) ? ctx->lds_bytes_d : ctx->lds_bytes;
+    if (lds_bytes) *lds_bytes = (ctx->dense && ctx->stage_cap_d) ? ctx->lds_bytes_d : ctx->sparse().lds_bytes;
+    return PFAC_OK;
+}
+
+int pfac_scan_staging(pfac_ctx *ctx, int *buffers, uint32_t *records_per_buffer) {
+    if (!ctx) return fail(nullptr, PFAC_E_ARG, "null context");
+    if (!ctx->have_table) return fail(ctx, PFAC_E_STATE, "no table uploaded");
+    const bool dense = ctx->dense && ctx->stage_cap_d;
+    if (buffers) *buffers = dense ? 1 : ctx->sparse().nbuf;
+    if (records_per_buffer) *records_per_buffer = dense ? ctx->stage_cap_d : ctx->sparse().stage_cap;
     return PFAC_OK;
 }
 

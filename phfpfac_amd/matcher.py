@@ -94,8 +94,10 @@ class GpuMatcher:
     def info(self) -> dict:
         v, t, g, l = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self._check(self._L.pfac_scan_info(self._ctx, C.byref(v), C.byref(t), C.byref(g), C.byref(l)))
+        nb, cap = C.c_int(), C.c_uint32()
+        self._check(self._L.pfac_scan_staging(self._ctx, C.byref(nb), C.byref(cap)))
         return {"variant": "tables_in_lds" if v.value == 0 else "tables_via_l2", "tile_bytes": t.value,
-                "grid_blocks": g.value, "lds_bytes": l.value}
+                "grid_blocks": g.value, "lds_bytes": l.value, "staging_buffers": nb.value, "staging_records": cap.value}
 
     # -- buffers ----------------------------------------------------------
     def reserve(self, slot: int = 0, input_bytes: int = 0, record_capacity: int = 0) -> None:

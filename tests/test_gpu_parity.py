@@ -107,6 +107,8 @@ def test_dictionary_dense_mode_kernels(width, env, resolve, monkeypatch):
                                  {"PFAC_WIDE": "1"},                      # 8-byte records in the heap (automata beyond 2^20 final states)
                                  {"PFAC_REC_BYTES": "4"},                 # 32-bit records where 16 bits would do
                                  {"PFAC_WIDE": "1", "PFAC_FORCE_L2": "1", "PFAC_DENSE": "1"},
+                                 {"PFAC_LAG": "1"}, {"PFAC_LAG": "2"},    # two / three staging buffers (emission one / two rounds late)
+                                 {"PFAC_LAG": "2", "PFAC_REC_BYTES": "4"},
                                  {"PFAC_L2F": "0"}, {"PFAC_L2F": "2"},    # level-2 filter off / lookup form where the SWAR form applies
                                  {"PFAC_L2F": "2", "PFAC_FORCE_L2": "1"}, {"PFAC_NO_SECF": "1", "PFAC_FORCE_L2": "1"}])
 @pytest.mark.parametrize("case", ["exp_x_1M_s1_w256", "xaa_x_1M_s1_w256", "all_x_1M_s3_w1024"])
@@ -795,3 +797,29 @@ def test_snort_scale_table_on_random_input(resolve):
             assert_same(table, gpu_records(table, data), pos, ids)
         finally:
             del os.environ[knob]
+
+
+def test_staging_layout_follows_the_match_density(tmp_path):
+    """Tables in LDS have two sparse staging layouts: three buffers (records leave at the top of a round; smaller
+    buffers) and two.  A context starts with three, falls back to two when more than 1/16 of a scan's tiles held more
+    records than the small buffers take (those tiles are walked twice), and returns when the input thins out.  Inputs
+    on either side of the three-buffer capacity (384 records per 4 KiB tile) and well past the two-buffer one, scanned
+    back to back by ONE context: every scan's records must equal the oracle's."""
+    pat = tmp_path / "p"
+    pat.write_bytes(b"a\nab\nabc\n")
+    table = PfacTable.from_file(str(pat), 256)
+    rng = np.random.default_rng(11)
+    n = 3 * 1024 * 1024 + 77
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        assert g.info()["variant"] == "tables_in_lds"
+        seen = []
+        assert g.info()["staging_buffers"] == 3
+        for density in (0.02, 0.08, 0.08, 0.02, 0.02, 0.3, 0.08, 0.02):
+            u = rng.random(n)
+            data = np.where(u < density, ord("a"), np.where(u < density + 0.3, ord("b"), ord("c"))).astype(np.uint8).tobytes()
+            rec = g.scan_bytes(data)
+            seen.append(g.info()["staging_buffers"])            # the layout the NEXT scan gets
+            pos, ids = oracle_pairs(str(pat), data)
+            assert_same(table, rec, pos, ids)
+        assert seen == [3, 2, 2, 3, 3, 1, 2, 3], seen
