@@ -667,6 +667,18 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
 #ifdef PFAC_ABL_NOSTAGE                        // ablation builds only: counted, never staged (stale records)
             if (true) continue;
 #endif
+            if (!DIRECT && totals[0] + totals[1] <= a.stage_cap) {
+                // everything fits (else the tile is walked again, DIRECT): no bound checks, two records per trip
+                const unsigned w0 = lpos | (st << 12);
+                for (unsigned m = keep[j]; m;) {
+                    stage[o] = w0 + (unsigned)__ffs(m) - 1u;
+                    m &= m - 1;
+                    if (m) stage[o + 1] = w0 + (unsigned)__ffs(m) - 1u;
+                    m &= m - 1;                         // (0 stays 0)
+                    o += 2;
+                }
+                continue;
+            }
             for (unsigned m = keep[j]; m; m &= m - 1) {
                 const unsigned pos = lpos + (__ffs(m) - 1);
                 if (DIRECT) put_record(a, wrun + o, pos, (unsigned)tile_base + pos, st);
@@ -763,7 +775,9 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
                              (stage[i + 4] & 0xFFFFu) | (stage[i + 5] << 16), (stage[i + 6] & 0xFFFFu) | (stage[i + 7] << 16)};
             *reinterpret_cast<u32x4 *>(out + base + i) = v;
         }
-        for (unsigned k = 0; k < 7u && i + k < cnt; k++) out[base + i + k] = (unsigned short)stage[i + k];   // the last 1..7 (one lane)
+        // the last 1..7 records: one lane each (not a loop in the one lane that stopped there: seven dependent LDS trips)
+        const unsigned tail = head + ((cnt - head) & ~7u);
+        if (tail + (unsigned)lane < cnt) out[base + tail + lane] = (unsigned short)stage[tail + lane];
         return;
     }
     unsigned *out = static_cast<unsigned *>(a.out);
@@ -780,11 +794,8 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
         const u32x4 v = {stage[i], stage[i + 1], stage[i + 2], stage[i + 3]};
         *reinterpret_cast<u32x4 *>(out + base + i) = v;
     }
-    if (i < cnt) {                             // the last 1..3 records (one lane)
-        out[base + i] = stage[i];
-        if (i + 1 < cnt) out[base + i + 1] = stage[i + 1];
-        if (i + 2 < cnt) out[base + i + 2] = stage[i + 2];
-    }
+    const unsigned tail = head + ((cnt - head) & ~3u);         // the last 1..3 records: one lane each
+    if (tail + (unsigned)lane < cnt) out[base + tail + lane] = stage[tail + lane];
 }
 
 // Root test: 16-bit mask of the lane's 16 bytes that have an edge out of the root.
@@ -1282,7 +1293,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 
 template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB = 2>
 __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLOCK)) void pfac_scan_kernel(ScanArgs a) {
-    static_assert(NB == 2 || (NB == 3 && TLDS), "three staging buffers: the kernels with their tables in LDS (the others have no LDS to spare)");
+    static_assert(NB == 2 || (NB == 3 && NW <= 2), "three staging buffers: the sparse-mode kernels (dense mode has one)");
     static_assert(!(TLDS && FUSED), "the fused table is for tables gathered through L2");
     static_assert(NW == (TLDS ? 1 : 2) || (FUSED && (NW == 3 || NW == 4)), "walks per lane: 1 (LDS tables), 2 (L2 tables), 3 (L2, fused), 4 (L2, fused, dense matches)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1861,15 +1872,16 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->kernel = k[ctx->variant == 0 ? 1 : (fused ? 2 : 0)][w8 ? 1 : 0][ctx->root_mode];
     // dense mode on fused L2 tables: four walks per lane (needs <= MAX_WAVES_NW4 waves per workgroup)
     ctx->kernel_d = ctx->kernel;
-    ctx->kernel3 = nullptr;
-    if (ctx->variant == 0) {
-        const void *k3[2][2] = {
-            {(const void *)pfac_scan_kernel<true, false, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, false, 1, false, 1, 3>},
-            {(const void *)pfac_scan_kernel<true, true, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, true, 1, false, 1, 3>}};
-        ctx->kernel3 = k3[w8 ? 1 : 0][ctx->root_mode];
+    {
+        const void *k3[3][2][2] = {
+            {{(const void *)pfac_scan_kernel<false, false, 0, false, 2, 3>, (const void *)pfac_scan_kernel<false, false, 1, false, 2, 3>},
+             {(const void *)pfac_scan_kernel<false, true, 0, false, 2, 3>, (const void *)pfac_scan_kernel<false, true, 1, false, 2, 3>}},
+            {{(const void *)pfac_scan_kernel<true, false, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, false, 1, false, 1, 3>},
+             {(const void *)pfac_scan_kernel<true, true, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, true, 1, false, 1, 3>}},
+            {{(const void *)pfac_scan_kernel<false, false, 0, true, 2, 3>, (const void *)pfac_scan_kernel<false, false, 1, true, 2, 3>},
+             {(const void *)pfac_scan_kernel<false, true, 0, true, 2, 3>, (const void *)pfac_scan_kernel<false, true, 1, true, 2, 3>}}};
+        ctx->kernel3 = k3[ctx->variant == 0 ? 1 : (fused ? 2 : 0)][w8 ? 1 : 0][ctx->root_mode];
         HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
-    } else {
-        ctx->lag2_ok = ctx->lag2 = false;
     }
     if (fused && !getenv("PFAC_NO_NW4")) {
         ctx->kernel_d = k[3][w8 ? 1 : 0][ctx->root_mode];
