@@ -316,8 +316,8 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 }
 
 // NWALK independent walks per lane, stepped together.  Walk w starts at tile-local position pos[w];
-// n[w] counts the final states reached, m[w][..] keeps the first MREG of them (MREG = 2: the first and the
-// latest, == the second when exactly two are met).  lim = first tile-local byte that may not be read.
+// n[w] counts the final states reached; m[w][..] keeps the latest MREG of them as a shift register, m[w][0] the latest
+// (= all of them, in reverse walk order, when n[w] <= MREG).  lim = first tile-local byte that may not be read.
 //  * all lanes step in lock step (trip count = deepest walk in the wave); dead lanes are predicated with
 //    selects instead of nested divergent branches -- far fewer exec-mask / scalar instructions per step;
 //  * input bytes come four at a time from one aligned 8-byte LDS read, so a step's only dependent
@@ -345,10 +345,12 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
                                       int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
     static_assert(MREG == 2 || MREG == 4, "two or four final states per walk in registers");
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
-    unsigned win[NWALK], p[NWALK], f[NWALK];
+    unsigned win[NWALK], left[NWALK], f[NWALK];                // left: bytes the walk may still read after its first
     int s[NWALK], rn[NWALK];                                   // rn: r[row of s] (FUSED)
-    bool go[NWALK], seen[NWALK];
+    bool go[NWALK];
+    unsigned k = 0;                                            // transitions made so far (the same for every walk: a scalar)
     const int sub = wbit - 8;                                  // FUSED needs wbit >= 8: row = state >> sub
+    int4 e4[NWALK];                                            // the fused slots of the last gather
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
         const unsigned lo = t32[pos[w] >> 2], hi = t32[(pos[w] >> 2) + 1];   // may run a few bytes past lim: never used
@@ -362,8 +364,8 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         n[w] = 0;
 #pragma unroll
         for (int k = 0; k < MREG; k++) m[w][k] = 0;
-        p[w] = pos[w] + 1;
-        go[w] = false; seen[w] = false;
+        left[w] = (deepf[w] && lim > pos[w] + 1u) ? lim - pos[w] - 1u : 0u;
+        go[w] = false;
         rn[w] = 0;
     }
     // account for the states just reached; false when no lane of the wave can go on.
@@ -373,16 +375,13 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
             const bool fin = (unsigned)s[w] < (unsigned)num_final;
-            if (MREG == 2) {                                   // first and latest (== second when n == 2)
-                m[w][0] = (fin && !seen[w]) ? (unsigned)s[w] : m[w][0];
-                m[w][1] = fin ? (unsigned)s[w] : m[w][1];
-                seen[w] = seen[w] || fin;
-            } else {
+            // the latest MREG final states as a shift register (m[0] = latest): one select each, no index compare;
+            // the caller puts them back in walk order
 #pragma unroll
-                for (int k = 0; k < MREG; k++) m[w][k] = (fin && n[w] == (unsigned)k) ? (unsigned)s[w] : m[w][k];
-            }
+            for (int j = MREG - 1; j > 0; j--) m[w][j] = fin ? m[w][j - 1] : m[w][j];
+            m[w][0] = fin ? (unsigned)s[w] : m[w][0];
             n[w] += fin ? 1u : 0u;
-            go[w] = s[w] >= 0 && p[w] < lim && deepf[w];
+            go[w] = s[w] >= 0 && k < left[w];
             any = any || go[w];
         }
         return __any(any);
@@ -391,11 +390,13 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     auto step = [&](int bi) {
         int row[NWALK], idx[NWALK];
         if (FUSED) {
+            constexpr bool MASKED = NWALK == 4 || MASK_GATHERS;
 #pragma unroll
             for (int w = 0; w < NWALK; w++) {
                 const int ch = (int)((win[w] >> (8 * bi)) & 0xFFu);
-                const int sg = go[w] ? s[w] : 0;
-                const int rg = go[w] ? rn[w] : 0;
+                // (masked gathers: a dead lane loads nothing, so its index need not be a valid one)
+                const int sg = MASKED ? s[w] : (go[w] ? s[w] : 0);
+                const int rg = MASKED ? rn[w] : (go[w] ? rn[w] : 0);
                 if (W8) {
                     row[w] = sg;
                     idx[w] = rg + ch;
@@ -404,27 +405,28 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
                     idx[w] = rg + (((sg & ((1 << sub) - 1)) << 8) | ch);
                 }
             }
-            int4 e[NWALK];
-            unsigned ic[NWALK];
+            // (a live walker's index is inside the slot array: it is padded to max(r) + width entries, and
+            // pfac_repack_kernel checked every displacement and state of the image)
 #pragma unroll
             for (int w = 0; w < NWALK; w++) {
-                ic[w] = min((unsigned)idx[w], (unsigned)ht_size - 1u);
-                if (NWALK == 4 || MASK_GATHERS) {
+                // (set before every gather although a dead lane's slot is only ever selected under go[w]: measured 15 %
+                // faster than carrying the stale value -- the gather then has no dependence on the register's old content)
+                e4[w] = make_int4(-1, -1, 0, 0);
+                if (MASKED) {
                     // dead lanes stay out of the gather: every lane of a gather costs the texture path an address
                     // cycle (64 per wave-instruction, against 16 for a coalesced 1 KiB load), and a round's later
                     // steps have few walkers left
-                    e[w] = make_int4(-1, -1, 0, 0);
-                    if (go[w]) e[w] = T4[ic[w]];
+                    if (go[w]) e4[w] = T4[idx[w]];
                 } else {
-                    e[w] = T4[ic[w]];
+                    e4[w] = T4[idx[w]];
                 }
             }
 #pragma unroll
             for (int w = 0; w < NWALK; w++) {
-                s[w] = (go[w] && ic[w] == (unsigned)idx[w] && e[w].x == row[w]) ? e[w].y : -1;
-                rn[w] = e[w].z;
-                p[w]++;
+                s[w] = (go[w] && e4[w].x == row[w]) ? e4[w].y : -1;
+                rn[w] = e4[w].z;
             }
+            k++;
             return;
         }
 #pragma unroll
@@ -444,14 +446,14 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         unsigned ic[NWALK];
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
-            ic[w] = min((unsigned)idx[w], (unsigned)ht_size - 1u);
+            ic[w] = min((unsigned)idx[w], (unsigned)ht_size - 1u);     // (the table ends at its last used slot)
             e[w] = T[ic[w]];
         }
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
             s[w] = (go[w] && ic[w] == (unsigned)idx[w] && e[w].x == row[w]) ? e[w].y : -1;
-            p[w]++;
         }
+        k++;
     };
     // FUSED: the first hashed step of a walk has no slot to take r[] from
     auto load_rn = [&]() {
@@ -475,8 +477,8 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             } else {
                 s[w] = go[w] ? nx : -1;
             }
-            p[w]++;
         }
+        k++;
     } else {
         if (FUSED && S0R) {
             // too many depth-1 states for dense rows: their r[] at least sits in LDS (by root byte), so the second
@@ -497,8 +499,9 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         if (!reached()) return;
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
-            const unsigned lo = t32[p[w] >> 2], hi = t32[(p[w] >> 2) + 1];
-            win[w] = __builtin_amdgcn_alignbyte(hi, lo, p[w] & 3u);
+            const unsigned p = pos[w] + 1u + k;                // next byte of the walk
+            const unsigned lo = t32[p >> 2], hi = t32[(p >> 2) + 1];
+            win[w] = __builtin_amdgcn_alignbyte(hi, lo, p & 3u);
         }
         step(0);
         if (!reached()) return;
@@ -525,9 +528,8 @@ __device__ __forceinline__ void put_record(const ScanArgs &a, unsigned long long
     }
 }
 
-// Same walk for the rare offsets where more than two patterns start: every final state from the
-// SECOND on goes to the LDS staging buffer (packed) or straight to global memory (the fast walk keeps
-// only the first and the latest final state).
+// Same walk for the rare offsets where more patterns start than the fast walk keeps final states in registers:
+// every final state goes to the LDS staging buffer (packed) or straight to global memory.
 template <bool W8, bool DIRECT>
 __device__ __forceinline__ void walk_store(const ScanArgs &a, const unsigned char *tile, const int *s0, const int *R, const int2 *T,
                                            unsigned pos, unsigned lim, unsigned *stage, unsigned long long ri, unsigned gpos) {
@@ -536,10 +538,8 @@ __device__ __forceinline__ void walk_store(const ScanArgs &a, const unsigned cha
     unsigned p = pos + 1;
     while (s >= 0) {
         if (s < a.num_final) {
-            if (n >= 1) {                                      // record 0 (m0) is written by the caller
-                if (DIRECT) put_record(a, ri + n, pos, gpos, (unsigned)s);
-                else if (ri + n < a.stage_cap) stage[ri + n] = pos | ((unsigned)s << 12);
-            }
+            if (DIRECT) put_record(a, ri + n, pos, gpos, (unsigned)s);
+            else if (ri + n < a.stage_cap) stage[ri + n] = pos | ((unsigned)s << 12);
             n++;
         }
         if (p >= lim) break;
@@ -594,6 +594,22 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
     }
     walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, deepf, lim,
                                         a.wbit, a.ht_size, a.num_final, n, m);
+    // the walk kept its latest MREG final states as a shift register (m[0] = latest): back into walk order
+#pragma unroll
+    for (int w = 0; w < NWALK; w++) {
+        const unsigned c = n[w];
+        if (MREG == 4) {
+            const unsigned a0 = m[w][0], a1 = m[w][1], a2 = m[w][2], a3 = m[w][3];
+            m[w][0] = c >= 4u ? a3 : (c == 3u ? a2 : (c == 2u ? a1 : a0));
+            m[w][1] = c >= 4u ? a2 : (c == 3u ? a1 : a0);
+            m[w][2] = c >= 4u ? a1 : a0;
+            m[w][3] = a0;
+        } else {
+            const unsigned a0 = m[w][0], a1 = m[w][1];
+            m[w][0] = c >= 2u ? a1 : a0;
+            m[w][1] = a0;
+        }
+    }
     // prefix sums of the counts, two walks per scan (16-bit fields; a walk reports < 1024 matches)
     unsigned ex[NWALK], total = 0;
 #pragma unroll
@@ -616,14 +632,14 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
         const unsigned gpos = (unsigned)tile_base + pos[w];
         if (DIRECT) {
             const unsigned long long ri = wrun + ex[w];
-            if (n[w] > 0) put_record(a, ri, pos[w], gpos, m[w][0]);
+            if (regs && n[w] > 0) put_record(a, ri, pos[w], gpos, m[w][0]);
 #pragma unroll
             for (int k = 1; k < MREG; k++)
                 if (regs && n[w] > (unsigned)k) put_record(a, ri + k, pos[w], gpos, m[w][k]);
             if (!regs) walk_store<W8, true>(a, tile, s0, R, T, pos[w], lim, nullptr, ri, gpos);
         } else {
             const unsigned ri = (unsigned)wrun + ex[w];        // tile-local record index: 32 bits are plenty
-            if (n[w] > 0 && ri < a.stage_cap) stage[ri] = pos[w] | (m[w][0] << 12);
+            if (regs && n[w] > 0 && ri < a.stage_cap) stage[ri] = pos[w] | (m[w][0] << 12);
 #pragma unroll
             for (int k = 1; k < MREG; k++)
                 if (regs && n[w] > (unsigned)k && ri + k < a.stage_cap) stage[ri + k] = pos[w] | (m[w][k] << 12);
@@ -1325,8 +1341,11 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
 // small service kernels
 
 // blob (int32 image, pfac.h) -> device layout {s0[256] | r[max_row] | pad | T[ht_size] int2 | idmap}
+// (*bad is set when the image would send a walk outside the tables: a row displacement outside the hash table, a root
+// or next state that is no state -- the fused walk indexes with these values unchecked; its slot array is padded to
+// max(r) + width entries, see pfac_fuse_kernel)
 __global__ void pfac_repack_kernel(const int *blob, int *s0, int *r, int2 *T, int *idmap, int max_row, int ht_size,
-                                   int num_final) {
+                                   int num_final, int state_num, int width, int *bad) {
     const int *b_s0 = blob + PFAC_BLOB_HEADER_WORDS;
     const int *b_r = b_s0 + 256;
     const int *b_HT = b_r + max_row;
@@ -1334,17 +1353,25 @@ __global__ void pfac_repack_kernel(const int *blob, int *s0, int *r, int2 *T, in
     const int *b_id = b_val + ht_size;
     const int stride = gridDim.x * blockDim.x;
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = i0; i < 256; i += stride) s0[i] = b_s0[i];
-    for (int i = i0; i < max_row; i += stride) r[i] = b_r[i];
-    for (int i = i0; i < ht_size; i += stride) T[i] = make_int2(b_HT[i], b_val[i]);
+    bool ok = true;
+    for (int i = i0; i < 256; i += stride) { s0[i] = b_s0[i]; ok = ok && b_s0[i] >= -1 && b_s0[i] < state_num; }
+    for (int i = i0; i < max_row; i += stride) { r[i] = b_r[i]; ok = ok && b_r[i] > -width && b_r[i] < ht_size; }
+    for (int i = i0; i < ht_size; i += stride) {
+        T[i] = make_int2(b_HT[i], b_val[i]);
+        ok = ok && (b_HT[i] < 0 || (b_val[i] >= -1 && b_val[i] < state_num));     // (an unowned slot's value is never used)
+    }
     for (int i = i0; i < num_final; i += stride) idmap[i] = b_id[i];
+    if (!ok) *bad = 1;
 }
 
 // Fused slots for tables gathered through L2 (PHF width >= 256): T4[i] = {owner row, next state, r[row of next], 0}.
-__global__ void pfac_fuse_kernel(const int2 *T, const int *r, int wbit, int ht_size, int max_row, int4 *T4) {
+// (slots [lo, hi) with lo <= min(r), hi >= max(r) + width: the table image holds [0, ht_size) -- displacements may be
+// negative and the image ends at its last used slot -- but the fused walk indexes unchecked; the slots outside the
+// image are empty ones.  T4 points at slot 0.)
+__global__ void pfac_fuse_kernel(const int2 *T, const int *r, int wbit, int ht_size, int max_row, int4 *T4, int lo, int hi) {
     const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ht_size; i += stride) {
-        const int2 e = T[i];
+    for (int i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
+        const int2 e = (i >= 0 && i < ht_size) ? T[i] : make_int2(-1, -1);
         int rn = -1;
         if (e.y >= 0) {
             const int row = e.y >> (wbit - 8);
@@ -1583,7 +1610,8 @@ struct pfac_ctx {
     size_t tab_bytes = 0;
     int *d_s0 = nullptr, *d_r = nullptr, *d_idmap = nullptr;
     int2 *d_T = nullptr;
-    int4 *d_T4 = nullptr;                 // fused slots (variant 1, width >= 256), else null
+    int4 *d_T4 = nullptr;                 // fused slots (variant 1, width >= 256), else null: slot 0 of ...
+    int4 *d_T4_alloc = nullptr;           // ... this allocation, which starts at slot min(0, min r)
     int width_bit = 0, num_final = 0, max_pat_len = 0, max_row = 0, ht_size = 0, state_num = 0;
     bool have_table = false;
     int variant = 1;
@@ -1850,11 +1878,19 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->dense_forced = getenv("PFAC_DENSE") ? atoi(getenv("PFAC_DENSE")) : -1;
     ctx->dense = ctx->dense_forced == 1 && ctx->stage_cap_d;
     const bool w8 = ctx->width_bit == 8;
-    if (ctx->d_T4) { HIP_TRY(ctx, hipFree(ctx->d_T4)); ctx->d_T4 = nullptr; }
+    if (ctx->d_T4_alloc) { HIP_TRY(ctx, hipFree(ctx->d_T4_alloc)); ctx->d_T4_alloc = ctx->d_T4 = nullptr; }
     if (fused) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_T4, (size_t)ctx->ht_size * sizeof(int4)));
+        std::vector<int> r_host((size_t)ctx->max_row);
+        HIP_TRY(ctx, hipMemcpy(r_host.data(), ctx->d_r, r_host.size() * 4, hipMemcpyDeviceToHost));
+        long long lo = 0, hi = ctx->ht_size;
+        for (int v : r_host) {
+            lo = v < lo ? v : lo;
+            hi = (long long)v + (1 << ctx->width_bit) > hi ? (long long)v + (1 << ctx->width_bit) : hi;
+        }
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_T4_alloc, (size_t)(hi - lo) * sizeof(int4)));
+        ctx->d_T4 = ctx->d_T4_alloc - lo;
         hipLaunchKernelGGL(pfac_fuse_kernel, dim3(256), dim3(256), 0, 0, ctx->d_T, ctx->d_r, ctx->width_bit, ctx->ht_size,
-                           ctx->max_row, ctx->d_T4);
+                           ctx->max_row, ctx->d_T4, (int)lo, (int)hi);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipDeviceSynchronize());
     }
@@ -1919,10 +1955,18 @@ int install_table(pfac_ctx *ctx, const int *d_blob, const int32_t *hdr, size_t n
     ctx->d_r = reinterpret_cast<int *>(base + off_r);
     ctx->d_T = reinterpret_cast<int2 *>(base + off_T);
     ctx->d_idmap = reinterpret_cast<int *>(base + off_id);
+    int *d_bad = reinterpret_cast<int *>(base + total - 16);
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, stream));
     hipLaunchKernelGGL(pfac_repack_kernel, dim3(256), dim3(256), 0, stream, d_blob, ctx->d_s0, ctx->d_r, ctx->d_T,
-                       ctx->d_idmap, max_row, ht_size, num_final);
+                       ctx->d_idmap, max_row, ht_size, num_final, state_num, width, d_bad);
     HIP_TRY(ctx, hipGetLastError());
+    int bad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (bad) {
+        ctx->have_table = false;
+        return fail(ctx, PFAC_E_ARG, "table image: a displacement or a state points outside the tables");
+    }
     ctx->width_bit = wbit; ctx->num_final = num_final; ctx->max_pat_len = max_pat_len;
     ctx->max_row = max_row; ctx->ht_size = ht_size; ctx->state_num = state_num;
     ctx->have_table = true;
@@ -1993,7 +2037,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
     }
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_d1) (void)hipFree(ctx->d_d1);
-    if (ctx->d_T4) (void)hipFree(ctx->d_T4);
+    if (ctx->d_T4_alloc) (void)hipFree(ctx->d_T4_alloc);
     if (ctx->d_bm2) (void)hipFree(ctx->d_bm2);
     delete ctx;
 }

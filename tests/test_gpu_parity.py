@@ -823,3 +823,28 @@ def test_staging_layout_follows_the_match_density(tmp_path):
             pos, ids = oracle_pairs(str(pat), data)
             assert_same(table, rec, pos, ids)
         assert seen == [3, 2, 2, 3, 3, 1, 2, 3], seen
+
+
+def test_malformed_table_image_is_refused_at_upload(resolve):
+    """The fused walk indexes its slot array unchecked (the array is padded to every index a well-formed image can
+    produce), so an image whose next states, root states or row displacements point outside the tables must not get
+    onto the device: the upload checks them all (pfac_repack_kernel) and fails with PFAC_E_ARG."""
+    table = PfacTable.from_file(resolve("xaa"), 256)
+    blob = np.array(table.blob(), dtype=np.int32)
+    max_row, ht = int(blob[8]), int(blob[9])
+    base_r, base_ht = 16 + 256, 16 + 256 + max_row
+    owned = np.flatnonzero(blob[base_ht:base_ht + ht] >= 0)
+    bad_images = []
+    b = blob.copy(); b[base_ht + ht + owned[len(owned) // 2]] = int(blob[6]) + 5; bad_images.append(b)     # a next state that is no state
+    b = blob.copy(); b[16 + ord("a")] = 1 << 30; bad_images.append(b)                                       # a root edge to nowhere
+    b = blob.copy(); b[base_r + 1] = ht + 7; bad_images.append(b)                                           # a row displaced past the table
+    b = blob.copy(); b[base_r + 2] = -(1 << 20); bad_images.append(b)                                       # ... or far before it
+    with GpuMatcher(0, 1) as g:
+        for b in bad_images:
+            with pytest.raises(PfacError, match="outside the tables"):
+                g.load_table(b)
+        g.load_table(blob)                                                                                   # the image itself is fine
+        data = open(resolve("1M"), "rb").read()[:50001]
+        rec = g.scan_bytes(data)
+    pos, ids = oracle_pairs(resolve("xaa"), data)
+    assert_same(table, rec, pos, ids)
