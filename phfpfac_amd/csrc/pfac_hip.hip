@@ -149,6 +149,8 @@ struct ScanArgs {
     const int4 *T4;                       // FUSED: {owner row, next state, r[row of next state], 0} per slot (tables via L2)
     int r_words, t_entries;
     int ht_size, wbit, num_final, halo;   // halo: bytes readable past a tile, multiple of 16
+    int rn_bias;                          // fused tables: T4 starts at slot -rn_bias (displacements may be negative); every index
+                                          // the fused walk forms is slot + rn_bias >= 0
     int shared_bytes, pw_bytes;           // LDS carve: shared region, then one region per wave
     const int *d1;                        // dense rows of the depth-1 states, d1_rows x 256 (or null)
     const unsigned char *d1idx;           // root byte -> dense row index
@@ -342,7 +344,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
                                       const int *D1, bool dense1, const int *D1R2, const int *S0R, const int *R, const int2 *T, const int4 *T4,
                                       const unsigned (&pos)[NWALK], const bool (&active)[NWALK], const bool (&deepf)[NWALK],
                                       unsigned lim, int wbit,
-                                      int ht_size, int num_final, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
+                                      int ht_size, int num_final, int rn_bias, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
     static_assert(MREG == 2 || MREG == 4, "two or four final states per walk in registers");
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
     unsigned win[NWALK], left[NWALK], f[NWALK];                // left: bytes the walk may still read after its first
@@ -386,6 +388,11 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         }
         return __any(any);
     };
+    // fused slot number i (biased: >= 0, see ScanArgs::rn_bias) by a 32-bit byte offset from the scalar base -- one
+    // shift, no 64-bit address arithmetic per lane
+    auto slot = [&](int i) -> int4 {
+        return *reinterpret_cast<const int4 *>(reinterpret_cast<const unsigned char *>(T4) + ((unsigned)i << 4));
+    };
     // one transition on byte number `bi` of the window (straight-line: dead lanes look up a harmless, valid slot)
     auto step = [&](int bi) {
         int row[NWALK], idx[NWALK];
@@ -416,9 +423,9 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
                     // dead lanes stay out of the gather: every lane of a gather costs the texture path an address
                     // cycle (64 per wave-instruction, against 16 for a coalesced 1 KiB load), and a round's later
                     // steps have few walkers left
-                    if (go[w]) e4[w] = T4[idx[w]];
+                    if (go[w]) e4[w] = slot(idx[w]);
                 } else {
-                    e4[w] = T4[idx[w]];
+                    e4[w] = slot(idx[w]);
                 }
             }
 #pragma unroll
@@ -459,7 +466,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     auto load_rn = [&]() {
         if (FUSED) {
 #pragma unroll
-            for (int w = 0; w < NWALK; w++) rn[w] = R[(go[w] ? s[w] : 0) >> sub];
+            for (int w = 0; w < NWALK; w++) rn[w] = R[(go[w] ? s[w] : 0) >> sub] + rn_bias;
         }
     };
     if (!reached()) return;
@@ -593,7 +600,7 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
         return nact;
     }
     walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, deepf, lim,
-                                        a.wbit, a.ht_size, a.num_final, n, m);
+                                        a.wbit, a.ht_size, a.num_final, a.rn_bias, n, m);
     // the walk kept its latest MREG final states as a shift register (m[0] = latest): back into walk order
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
@@ -899,14 +906,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     }
     int *d1r2_l = reinterpret_cast<int *>(smem + SH_D1 + a.d1_rows * 1024);
     if (FUSED && a.d1_n2 > 0)
-        for (int i = tid; i < a.d1_n2; i += blockDim.x) d1r2_l[i] = a.d1r2[i];
+        for (int i = tid; i < a.d1_n2; i += blockDim.x) d1r2_l[i] = a.d1r2[i] + a.rn_bias;
     // FUSED without dense rows: r[] of the depth-1 states by root byte, in the (unused) dense-row region
     int *s0r_l = reinterpret_cast<int *>(smem + SH_D1);
     const bool have_s0r = FUSED && a.d1_rows == 0;
     if (have_s0r)
         for (int i = tid; i < 256; i += blockDim.x) {
             const int v = a.s0[i];
-            s0r_l[i] = v >= 0 ? a.r[v >> (a.wbit - 8)] : 0;
+            s0r_l[i] = v >= 0 ? a.r[v >> (a.wbit - 8)] + a.rn_bias : 0;
         }
     const Dense1 d1 = {d1idx_l, d1_l, a.d1_rows > 0, (FUSED && a.d1_n2 > 0) ? d1r2_l : nullptr, have_s0r ? s0r_l : nullptr};
     const int sh_tab = SH_D1 + a.d1_rows * 1024;     // (the packed rows' r[] and LDS tables never coexist)
@@ -1372,12 +1379,13 @@ __global__ void pfac_fuse_kernel(const int2 *T, const int *r, int wbit, int ht_s
     const int stride = gridDim.x * blockDim.x;
     for (int i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
         const int2 e = (i >= 0 && i < ht_size) ? T[i] : make_int2(-1, -1);
-        int rn = -1;
+        int rn = -1;                           // (.z: r[row of the next state], biased like every fused index: slot - lo)
+        bool have = false;
         if (e.y >= 0) {
             const int row = e.y >> (wbit - 8);
-            if (row < max_row) rn = r[row];
+            if (row < max_row) { rn = r[row]; have = true; }
         }
-        T4[i] = make_int4(e.x, e.y, rn, 0);
+        T4[i] = make_int4(e.x, e.y, have ? rn - lo : 0, 0);
     }
 }
 
@@ -1611,7 +1619,8 @@ struct pfac_ctx {
     int *d_s0 = nullptr, *d_r = nullptr, *d_idmap = nullptr;
     int2 *d_T = nullptr;
     int4 *d_T4 = nullptr;                 // fused slots (variant 1, width >= 256), else null: slot 0 of ...
-    int4 *d_T4_alloc = nullptr;           // ... this allocation, which starts at slot min(0, min r)
+    int4 *d_T4_alloc = nullptr;           // ... this allocation, which starts at slot min(0, min r) = -rn_bias
+    int rn_bias = 0;
     int width_bit = 0, num_final = 0, max_pat_len = 0, max_row = 0, ht_size = 0, state_num = 0;
     bool have_table = false;
     int variant = 1;
@@ -1879,6 +1888,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->dense = ctx->dense_forced == 1 && ctx->stage_cap_d;
     const bool w8 = ctx->width_bit == 8;
     if (ctx->d_T4_alloc) { HIP_TRY(ctx, hipFree(ctx->d_T4_alloc)); ctx->d_T4_alloc = ctx->d_T4 = nullptr; }
+    ctx->rn_bias = 0;
     if (fused) {
         std::vector<int> r_host((size_t)ctx->max_row);
         HIP_TRY(ctx, hipMemcpy(r_host.data(), ctx->d_r, r_host.size() * 4, hipMemcpyDeviceToHost));
@@ -1887,8 +1897,10 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
             lo = v < lo ? v : lo;
             hi = (long long)v + (1 << ctx->width_bit) > hi ? (long long)v + (1 << ctx->width_bit) : hi;
         }
+        if (hi - lo >= (1ll << 28)) return fail(ctx, PFAC_E_ARG, "table image: more than 2^28 hash slots");
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_T4_alloc, (size_t)(hi - lo) * sizeof(int4)));
         ctx->d_T4 = ctx->d_T4_alloc - lo;
+        ctx->rn_bias = (int)-lo;
         hipLaunchKernelGGL(pfac_fuse_kernel, dim3(256), dim3(256), 0, 0, ctx->d_T, ctx->d_r, ctx->width_bit, ctx->ht_size,
                            ctx->max_row, ctx->d_T4, (int)lo, (int)hi);
         HIP_TRY(ctx, hipGetLastError());
@@ -2167,7 +2179,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.bm2 = ctx->d_bm2; a.bm2_rows = ctx->bm2_rows; a.sh_bm2 = ctx->sh_bm2;
         a.sec2 = ctx->d_bm2 + 256 * 32; a.sec_filter = ctx->sec_filter;
         a.spin_max = ctx->spin_max; a.fault = ctx->fault;
-        a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T; a.T4 = ctx->d_T4;
+        a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T; a.T4 = ctx->d_T4_alloc; a.rn_bias = ctx->rn_bias;
         a.r_words = ctx->max_row; a.t_entries = ctx->ht_size;
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
         a.halo = ctx->halo;
