@@ -58,6 +58,14 @@ if "SQ_WAVE_CYCLES" in out:
             out["frac_" + k] = round(out[k] / out["SQ_WAVE_CYCLES"], 4)
 if "SQ_LDS_IDX_ACTIVE" in out and out["SQ_LDS_IDX_ACTIVE"]:
     out["lds_bank_conflict_frac"] = round(out.get("SQ_LDS_BANK_CONFLICT", 0) / out["SQ_LDS_IDX_ACTIVE"], 4)
+if out.get("GRBM_GUI_ACTIVE") and out.get("SQ_INSTS_VALU"):
+    # busy fractions of the execution units over the launch: GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU
+    # instruction occupies its SIMD (16 lanes wide, 4 per CU) for 4 cycles; the scalar unit and the LDS are one per CU
+    cyc = out["GRBM_GUI_ACTIVE"] / 8.0
+    out["util"] = {"valu_pipe": round(out["SQ_INSTS_VALU"] * 4 / (1024 * cyc), 3),
+                   "salu": round(out.get("SQ_INSTS_SALU", 0) / (256 * cyc), 3),
+                   "lds": round(out.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * cyc), 3),
+                   "note": "VALU: wave-instructions x 4 cycles / (1024 SIMDs x kernel cycles); SALU, LDS: per CU"}
 for row in csv.DictReader(open(ks)):
     if "pfac_scan_kernel" in row["Name"]:
         out.setdefault("kernel_stats", []).append({"name": row["Name"][:120], "calls": int(row["Calls"]),
