@@ -2,7 +2,8 @@
 count checked against a closed form (text input has period 402); scans below 1 MiB also have their expanded records
 compared with the CPU oracle record for record (heap placement, tile index, chunk boundaries).
 Looks for rare protocol failures (timeouts surface as PFAC_E_INTERNAL), count drift and misplaced records.
-usage: soak.py [seconds] [seed] [own]      ("own": the two slots keep their own streams -> two grids at once)"""
+usage: soak.py [seconds] [seed] [own] [dict]      ("own": the two slots keep their own streams -> two grids at once;
+"dict": the 7 989-word dictionary instead of experimentpattern -- tables via L2, dense staging, four walks per lane)"""
 import os
 import sys
 import time
@@ -23,7 +24,12 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 N = 1 << 30
 buf = torch.empty(N + 4096, dtype=torch.uint8, device="cuda:0")
 pat = os.path.join(DATA, "experimentpattern")
+if "dict" in sys.argv:
+    import tempfile
+    pat = os.path.join(tempfile.mkdtemp(), "all.pat")
+    open(pat, "wb").write(b"".join(open(os.path.join(DATA, p), "rb").read() for p in ("xaa", "xab", "xac", "xad")))
 table = PfacTable.from_file(pat, 256)
+HALO = max(table.max_pat_len, 8)
 
 # matches starting at each phase of the period (walks never cross more than max_pat_len bytes)
 o = Oracle(pat, 1, 1)
@@ -40,7 +46,7 @@ def expected(start, n_owned, n_avail):
     idx = (ph + np.arange(rem)) % 402
     cnt = int(full * cum[402] + per_phase[idx].sum())
     # cut-off at the end of the readable range: recount the last few offsets exactly
-    k = min(n_owned, 8)
+    k = min(n_owned, HALO)
     tail_lo = start + n_owned - k
     data = tiled_bytes(start + n_avail - tail_lo, para, phase=tail_lo % 402)
     tp, _ = o.scan_spec(data)
@@ -54,8 +60,8 @@ with GpuMatcher(0, 2) as g:
         g.set_stream(1, g.stream_handle(0))
     g.load_table(table)
     g.fill_tiled(buf, N, para)
-    g.reserve(0, 0, N // 8)
-    g.reserve(1, 0, N // 8)
+    g.reserve(0, 0, N // 2 if "dict" in sys.argv else N // 8)
+    g.reserve(1, 0, N // 2 if "dict" in sys.argv else N // 8)
     t0 = time.time()
     scans = 0
     checked = 0
@@ -71,7 +77,7 @@ with GpuMatcher(0, 2) as g:
         else:
             n_owned = int(rng.integers(1, 64)) * 4096 + int(rng.integers(-17, 18))
         start = int(rng.integers(0, (N - n_owned) // 16 + 1)) * 16
-        halo = int(rng.integers(0, 4))
+        halo = int(rng.integers(0, HALO))
         n_avail = min(N - start, n_owned + halo)
         sl = scans & 1
         g.scan_async(n_owned, n_avail, d_input=int(buf.data_ptr()) + start, slot=sl)
