@@ -69,7 +69,7 @@ constexpr int MLANE = MSUB / WAVE;         // 32 bytes per lane -> one 32-bit su
 constexpr int HALO_MAX = 1024;             // >= max_pat_len - 1 (patterns are < 1024 bytes), multiple of 16
 constexpr int QCAP = SUB / 2 + 4 * WAVE;   // survivor FIFO: < one round (at most 4 x 64) carried over + up to 512 appended at a time
 #ifndef PFAC_CAPW
-#define PFAC_CAPW 384
+#define PFAC_CAPW 256
 #endif
 constexpr int CAPW = PFAC_CAPW;            // records staged in LDS per tile per buffer (more -> synchronous re-walk)
 constexpr int PACK_STATE_BITS = 20;        // staged record = pos:12 | state:20 (larger automata re-walk)
@@ -84,11 +84,13 @@ constexpr int SH_S0 = SH_HDR + 2048;
 constexpr int SH_FTAB = SH_S0 + 256 * 4;
 constexpr int SH_D1IDX = SH_FTAB + 8 * 256 * 2; // 256 x u8: dense-row index of the depth-1 state reached on each root byte
 constexpr int SH_FIN = SH_D1IDX + 256;     // 256 x u8: 1 where the depth-1 state reached on that root byte is final
-constexpr int SH_D1 = SH_FIN + 256;        // d1_rows dense rows int32[256] (the hot first-level transition rows)
-constexpr int D1_MAX = 32;                 // at most this many depth-1 states get a dense row (else none do)
+constexpr int SH_COLMAP = SH_FIN + 256;    // 256 x u8: column of the dense rows a second byte maps to (the last column = no edge)
+constexpr int SH_D1 = SH_COLMAP + 256;     // d1_rows dense rows int32[d1_stride] (the hot first-level transition rows), only the
+                                           // columns of bytes that ARE the second byte of some pattern + one "no edge" column
+constexpr int D1_LDS_MAX = 32 * 1024;      // the depth-1 states get dense rows when rows x columns x 4 B fit this (else none do)
 constexpr int D1_STATE_BITS = 20;          // packed dense-row entry (FUSED): state | index of its r[] << 20
 constexpr int D1_N2_MAX = 2048;            // ... so at most this many depth-2 states (the entry stays positive)
-// the PHF tables (variant 0) follow the dense rows: SH_D1 + d1_rows * 1024; the 2-byte-prefix bitmap (bm2_rows x 32
+// the PHF tables (variant 0) follow the dense rows: SH_D1 + d1_lds_bytes; the 2-byte-prefix bitmap (bm2_rows x 32
 // bytes) sits at ScanArgs::sh_bm2, behind them
 #ifndef PFAC_L2F_UNROLL
 #define PFAC_L2F_UNROLL 1
@@ -110,7 +112,7 @@ constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position |
 // retire through one in-order counter (vmcnt) the next round's wait for its tile also waits for their write
 // acknowledgements (measured: 6 % of the headline kernel).
 constexpr int NBUF_MAX = 3;
-constexpr int CAPW3_MIN = 256;             // the three-buffer layout needs room for this many records per buffer
+constexpr int CAPW3_MIN = 192;             // the three-buffer layout needs room for this many records per buffer
 constexpr int PW_FIXED_1BUF = WTILE + QCAP * 2;              // + nbuf * stage_cap * 4
 // Dense mode (most tiles hold more matches than CAPW, e.g. a dictionary on text): ONE big staging buffer per
 // wave and synchronous emission -- fewer waves fit, but a tile is walked once instead of twice.
@@ -152,9 +154,13 @@ struct ScanArgs {
     int rn_bias;                          // fused tables: T4 starts at slot -rn_bias (displacements may be negative); every index
                                           // the fused walk forms is slot + rn_bias >= 0
     int shared_bytes, pw_bytes;           // LDS carve: shared region, then one region per wave
-    const int *d1;                        // dense rows of the depth-1 states, d1_rows x 256 (or null)
+    const int *d1;                        // dense rows of the depth-1 states, d1_rows x 256 (or null); in LDS: d1_rows x d1_stride
     const unsigned char *d1idx;           // root byte -> dense row index
+    const unsigned char *d1_colmap;       // [256] second byte -> LDS column (d1_stride - 1: no pattern has it as second byte)
+    const unsigned char *d1_colbyte;      // [d1_ncols] the byte of each LDS column
     int d1_rows;                          // 0: no dense level
+    int d1_stride, d1_ncols, d1_lds_bytes;  // LDS row length in words (columns, + 1 "no edge" unless all 256 are used);
+                                          // columns; bytes of the LDS rows (multiple of 16)
     const int *d1r2;                      // FUSED + packed dense rows: r[] of the depth-2 states, d1_n2 words (else null)
     int d1_n2;                            // > 0: a dense-row entry is  state | index into d1r2 << 20  (or -1)
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
@@ -341,7 +347,7 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 //    and stops there.
 template <bool W8, int NWALK, bool FUSED, int MREG, int ROOT>
 __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, int root_state, const unsigned char *d1idx,
-                                      const int *D1, bool dense1, const int *D1R2, const int *S0R, const int *R, const int2 *T, const int4 *T4,
+                                      const unsigned char *colmap, unsigned d1_stride, const int *D1, bool dense1, const int *D1R2, const int *S0R, const int *R, const int2 *T, const int4 *T4,
                                       const unsigned (&pos)[NWALK], const bool (&active)[NWALK], const bool (&deepf)[NWALK],
                                       unsigned lim, int wbit,
                                       int ht_size, int num_final, int rn_bias, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
@@ -474,7 +480,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         // second byte: the depth-1 state's row is dense in LDS -- one lookup, no hash, no owner check
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
-            const int nx = D1[(go[w] ? f[w] : 0u) * 256u + ((win[w] >> 8) & 0xFFu)];
+            const int nx = D1[(go[w] ? f[w] : 0u) * d1_stride + colmap[(win[w] >> 8) & 0xFFu]];
             if (FUSED && D1R2) {
                 // packed entry: the depth-2 state and where its r[] sits in LDS -- the walk's first hashed step
                 // needs no r[] gather either
@@ -556,6 +562,7 @@ __device__ __forceinline__ void walk_store(const ScanArgs &a, const unsigned cha
 }
 
 struct Dense1 {
+    const unsigned char *colmap;
     const unsigned char *idx;
     const int *rows;
     bool on;
@@ -599,7 +606,7 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
         }
         return nact;
     }
-    walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, deepf, lim,
+    walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.colmap, (unsigned)a.d1_stride, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, deepf, lim,
                                         a.wbit, a.ht_size, a.num_final, a.rn_bias, n, m);
     // the walk kept its latest MREG final states as a shift register (m[0] = latest): back into walk order
 #pragma unroll
@@ -898,13 +905,18 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     }
     unsigned char *d1idx_l = smem + SH_D1IDX;
     int *d1_l = reinterpret_cast<int *>(smem + SH_D1);
+    unsigned char *colmap_l = smem + SH_COLMAP;
     if (a.d1_rows > 0) {
-        for (int i = tid; i < 256; i += blockDim.x) d1idx_l[i] = a.d1idx[i];
-        for (int i = tid; i < a.d1_rows * 256; i += blockDim.x) d1_l[i] = a.d1[i];
+        for (int i = tid; i < 256; i += blockDim.x) { d1idx_l[i] = a.d1idx[i]; colmap_l[i] = a.d1_colmap[i]; }
+        // (only the columns of bytes some pattern has second; the last column of a row: no edge)
+        for (int i = tid; i < a.d1_rows * a.d1_stride; i += blockDim.x) {
+            const int row = i / a.d1_stride, c = i - row * a.d1_stride;
+            d1_l[i] = c < a.d1_ncols ? a.d1[row * 256 + a.d1_colbyte[c]] : -1;
+        }
     } else {
-        for (int i = tid; i < 256; i += blockDim.x) d1idx_l[i] = 0;
+        for (int i = tid; i < 256; i += blockDim.x) { d1idx_l[i] = 0; colmap_l[i] = 0; }
     }
-    int *d1r2_l = reinterpret_cast<int *>(smem + SH_D1 + a.d1_rows * 1024);
+    int *d1r2_l = reinterpret_cast<int *>(smem + SH_D1 + a.d1_lds_bytes);
     if (FUSED && a.d1_n2 > 0)
         for (int i = tid; i < a.d1_n2; i += blockDim.x) d1r2_l[i] = a.d1r2[i] + a.rn_bias;
     // FUSED without dense rows: r[] of the depth-1 states by root byte, in the (unused) dense-row region
@@ -915,8 +927,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             const int v = a.s0[i];
             s0r_l[i] = v >= 0 ? a.r[v >> (a.wbit - 8)] + a.rn_bias : 0;
         }
-    const Dense1 d1 = {d1idx_l, d1_l, a.d1_rows > 0, (FUSED && a.d1_n2 > 0) ? d1r2_l : nullptr, have_s0r ? s0r_l : nullptr};
-    const int sh_tab = SH_D1 + a.d1_rows * 1024;     // (the packed rows' r[] and LDS tables never coexist)
+    const Dense1 d1 = {colmap_l, d1idx_l, d1_l, a.d1_rows > 0, (FUSED && a.d1_n2 > 0) ? d1r2_l : nullptr, have_s0r ? s0r_l : nullptr};
+    const int sh_tab = SH_D1 + a.d1_lds_bytes;       // (the packed rows' r[] and LDS tables never coexist)
     const int *R = a.r;
     const int2 *T = a.T;
     if (TLDS) {
@@ -1639,7 +1651,7 @@ struct pfac_ctx {
     bool dense = false;                   // current staging mode (adapts to the match density seen by the last scan)
     int dense_forced = -1;                // PFAC_DENSE=0/1 pins the mode
     int *d_d1 = nullptr;                  // dense depth-1 rows + (after them) the 256-byte row index
-    int d1_rows = 0;
+    int d1_rows = 0, d1_stride = 0, d1_ncols = 0, d1_lds_bytes = 0;
     int d1_n2 = 0;                        // > 0: dense rows are packed (fused tables), r[] of the depth-2 states follows them
     int grid_blocks = 0;
     int rec_bytes = 4;                    // record form: 2 (<= 16 final states), 4 (<= 2^20), 8 bytes (pfac_record)
@@ -1748,15 +1760,19 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         d1idx[i] = 0;
         if (s0_host[i] >= 0) { d1state[fan] = s0_host[i]; d1idx[i] = (unsigned char)(fan < 255 ? fan : 255); fan++; rb = i; }
     }
-    ctx->d1_rows = (fan >= 1 && fan <= D1_MAX && !getenv("PFAC_NO_D1")) ? fan : 0;
+    // (rows are built in device memory in full, 256 columns; LDS takes the columns that have an edge in some row)
+    ctx->d1_rows = (fan >= 1 && fan <= 255 && !getenv("PFAC_NO_D1")) ? fan : 0;
+    ctx->d1_stride = 0; ctx->d1_lds_bytes = 0;
     // tables via L2 and PHF width >= 256: fused slots, one gather per step
     const bool fused = ctx->variant == 1 && ctx->width_bit >= 8 && !getenv("PFAC_NO_FUSE");
     ctx->d1_n2 = 0;
     if (ctx->d_d1) { HIP_TRY(ctx, hipFree(ctx->d_d1)); ctx->d_d1 = nullptr; }
     if (ctx->d1_rows) {
-        // layout: rows | 256-byte row index | the depth-1 states | (packed rows) r[] of the depth-2 states | counter
+        // layout: rows | 256-byte row index | the depth-1 states | (packed rows) r[] of the depth-2 states | counter |
+        // column map | column bytes
         const size_t off_r2 = (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_d1, off_r2 + (size_t)D1_N2_MAX * 4 + 16));
+        const size_t off_col = off_r2 + (size_t)D1_N2_MAX * 4 + 16;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_d1, off_col + 512));
         unsigned char *b = reinterpret_cast<unsigned char *>(ctx->d_d1);
         int *d_state = reinterpret_cast<int *>(b + (size_t)ctx->d1_rows * 1024 + 256);
         HIP_TRY(ctx, hipMemcpy(b + (size_t)ctx->d1_rows * 1024, d1idx, 256, hipMemcpyHostToDevice));
@@ -1765,10 +1781,33 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
                            ctx->width_bit, ctx->ht_size, ctx->d_d1);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipDeviceSynchronize());
-        if (fused && ctx->state_num <= (1 << D1_STATE_BITS) && !getenv("PFAC_NO_D1PACK")) {
-            // how many depth-2 states are there?  (host copy of the rows: at most 32 KiB)
-            std::vector<int> rows((size_t)ctx->d1_rows * 256);
-            HIP_TRY(ctx, hipMemcpy(rows.data(), ctx->d_d1, rows.size() * 4, hipMemcpyDeviceToHost));
+        // which bytes are the second byte of some pattern: the LDS rows keep those columns only (host copy of the
+        // rows: at most 255 KiB); too many rows x columns for LDS: no dense level
+        std::vector<int> rows((size_t)ctx->d1_rows * 256);
+        HIP_TRY(ctx, hipMemcpy(rows.data(), ctx->d_d1, rows.size() * 4, hipMemcpyDeviceToHost));
+        unsigned char colmap[256], colbyte[256];
+        int ncols = 0;
+        for (int c = 0; c < 256; c++) {
+            bool used = false;
+            for (int f = 0; f < ctx->d1_rows && !used; f++) used = rows[(size_t)f * 256 + c] >= 0;
+            if (used) colbyte[ncols++] = (unsigned char)c;
+        }
+        const int stride = ncols < 256 ? ncols + 1 : 256;      // one more column, "no edge", unless every byte has its own
+        for (int c = 0; c < 256; c++) colmap[c] = (unsigned char)(ncols & 255);
+        for (int k = 0; k < ncols; k++) colmap[colbyte[k]] = (unsigned char)k;
+        if ((size_t)ctx->d1_rows * stride * 4 > (size_t)D1_LDS_MAX) {
+            HIP_TRY(ctx, hipFree(ctx->d_d1));
+            ctx->d_d1 = nullptr;
+            ctx->d1_rows = 0;
+        } else {
+            ctx->d1_stride = stride;
+            ctx->d1_ncols = ncols;
+            ctx->d1_lds_bytes = (int)align_up((size_t)ctx->d1_rows * ctx->d1_stride * 4, 16);
+            HIP_TRY(ctx, hipMemcpy(b + off_col, colmap, 256, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(b + off_col + 256, colbyte, 256, hipMemcpyHostToDevice));
+        }
+        if (ctx->d1_rows && fused && ctx->state_num <= (1 << D1_STATE_BITS) && !getenv("PFAC_NO_D1PACK")) {
+            // how many depth-2 states are there?
             int n2 = 0;
             for (int v : rows) n2 += v >= 0;
             if (n2 >= 1 && n2 <= D1_N2_MAX) {
@@ -1783,7 +1822,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
             }
         }
     }
-    ctx->shared_bytes = SH_D1 + ctx->d1_rows * 1024 + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 4, 16));
+    ctx->shared_bytes = SH_D1 + ctx->d1_lds_bytes + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 4, 16));
     if (fused && ctx->d1_rows == 0) ctx->shared_bytes += 1024;   // r[] of the depth-1 states by root byte
     // ---- level-2 filter: the 2-byte-prefix bitmap is built on the device from the uploaded tables; a single-edge
     // root with at most two grandchildren gets the bit-parallel form (their bytes), everything else the lookup form
@@ -2184,7 +2223,11 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.ht_size = ctx->ht_size; a.wbit = ctx->width_bit; a.num_final = ctx->num_final;
         a.halo = ctx->halo;
         a.shared_bytes = ctx->shared_bytes; a.pw_bytes = dense ? ctx->pw_bytes_d : L.pw_bytes;
-        a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows;
+        a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows; a.d1_stride = ctx->d1_stride; a.d1_ncols = ctx->d1_ncols; a.d1_lds_bytes = ctx->d1_lds_bytes;
+        a.d1_colmap = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 + 256 +
+                                      (size_t)ctx->d1_rows * 4 + (size_t)D1_N2_MAX * 4 + 16
+                                : nullptr;
+        a.d1_colbyte = a.d1_colmap ? a.d1_colmap + 256 : nullptr;
         a.d1_n2 = ctx->d1_n2;
         a.d1r2 = ctx->d1_n2 ? reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ctx->d_d1) +
                                                             (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4)
