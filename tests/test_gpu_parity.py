@@ -848,3 +848,38 @@ def test_malformed_table_image_is_refused_at_upload(resolve):
         rec = g.scan_bytes(data)
     pos, ids = oracle_pairs(resolve("xaa"), data)
     assert_same(table, rec, pos, ids)
+
+
+@pytest.mark.parametrize("force_l2", [False, True])
+@pytest.mark.parametrize("n_first,n_second", [(120, 40), (30, 256), (100, 256), (255, 3), (256, 5)])
+def test_dense_depth1_rows_by_column(n_first, n_second, force_l2, tmp_path, monkeypatch):
+    """The dense rows of the depth-1 states sit in LDS with only the columns of bytes that are some pattern's second
+    byte (+ a "no edge" column): many first bytes x few second bytes (120 x 40), every byte a second byte (no spare
+    column: 30 x 256), too much for LDS (100 x 256: the walk hashes its second byte), 255 depth-1 states, and one too
+    many for a row index (256) -- tables in LDS and through L2, records == oracle."""
+    if force_l2:
+        monkeypatch.setenv("PFAC_FORCE_L2", "1")
+    rng = np.random.default_rng(n_first * 1000 + n_second)
+    firsts = rng.permutation(256)[:n_first].astype(np.uint8)
+    firsts = firsts[firsts != 10][: n_first] if n_first < 256 else np.array([b for b in range(256) if b != 10], dtype=np.uint8)
+    seconds = rng.permutation(np.array([b for b in range(256) if b != 10], dtype=np.uint8))[: min(n_second, 255)]
+    pats = set()
+    for f in firsts:                                       # every first byte with a few of the second bytes, some going deeper
+        for sb in rng.choice(seconds, size=min(6, len(seconds)), replace=False):
+            tail = bytes(int(x) for x in rng.choice(seconds, size=int(rng.integers(0, 4))))
+            pats.add(bytes([int(f), int(sb)]) + tail)
+    for sb in seconds:                                     # ... and every second byte used at least once
+        pats.add(bytes([int(firsts[int(rng.integers(0, len(firsts)))]), int(sb)]))
+    pf = tmp_path / "p"
+    pf.write_bytes(b"\n".join(sorted(pats)) + b"\n")
+    table = PfacTable.from_file(str(pf), 256)
+    alphabet = np.union1d(firsts, seconds)
+    data = alphabet[rng.integers(0, alphabet.size, 150_001)].astype(np.uint8)
+    plist = sorted(pats)
+    for at in rng.integers(0, data.size - 8, 4000):       # ... with patterns planted all over it
+        pt = plist[int(rng.integers(0, len(plist)))]
+        data[at:at + len(pt)] = np.frombuffer(pt, dtype=np.uint8)
+    rec = gpu_records(table, data)
+    pos, ids = oracle_pairs(str(pf), data)
+    assert pos.size > 3000
+    assert_same(table, rec, pos, ids)
