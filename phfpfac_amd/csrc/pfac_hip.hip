@@ -43,6 +43,7 @@
  *            tiles are like that.
  */
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <stdint.h>
 #include <stdio.h>
@@ -2207,7 +2208,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
     const uint64_t n_batches = (n_tiles + wpb - 2) / (wpb - 1);
     unsigned *const cur = s.d_ctlbuf[s.flip], *const nxt = s.d_ctlbuf[1 - s.flip];
     if (n_tiles > 0 && !s.clean[s.flip]) HIP_TRY(ctx, hipMemsetAsync(cur, 0, CTL_REGION, s.stream));
-    HIP_TRY(ctx, hipEventRecord(s.ev0, s.stream));
+    if (n_tiles == 0) HIP_TRY(ctx, hipEventRecord(s.ev0, s.stream));
     if (n_tiles > 0) {
         ScanArgs a;
         a.in = in; a.n_owned = n_owned; a.n_avail = n_avail;
@@ -2263,12 +2264,15 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         if (chunk > (1u << 22)) chunk = 1u << 22;
         a.chunk = chunk >= 1024 ? (unsigned)chunk : 0u;
         void *kargs[] = {&a};
-        HIP_TRY(ctx, hipLaunchKernel(dense ? ctx->kernel_d : (ctx->lag2 ? ctx->kernel3 : ctx->kernel), dim3((unsigned)grid), dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream));
+        // the slot's two events ride on the dispatch itself (start / stop of THIS kernel): no barrier packets of their own
+        // in front of and behind every scan
+        HIP_TRY(ctx, hipExtLaunchKernel(dense ? ctx->kernel_d : (ctx->lag2 ? ctx->kernel3 : ctx->kernel), dim3((unsigned)grid),
+                                        dim3(WAVE * wpb), kargs, (size_t)lds_bytes, s.stream, s.ev0, s.ev1, 0));
         s.clean[s.flip] = false;               // used by this scan
         s.clean[1 - s.flip] = true;            // zeroed by this scan
         s.flip = 1 - s.flip;
     }
-    HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
+    if (n_tiles == 0) HIP_TRY(ctx, hipEventRecord(s.ev1, s.stream));
     return PFAC_OK;
 }
 
