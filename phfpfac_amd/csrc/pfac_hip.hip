@@ -1253,6 +1253,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             }
         }
 
+#ifdef PFAC_ABL_NOKEEP                         // ablation builds only: survivors classified, then dropped (no records)
+        asm volatile("" :: "v"(keep[0]), "v"(keep[1]), "v"(deep[0]), "v"(deep[1]));
+        keep[0] = keep[1] = deep[0] = deep[1] = 0;
+#endif
         PFAC_STAMP(trace, 6);
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
         unsigned *stage = stage0 + buf * a.stage_cap;
