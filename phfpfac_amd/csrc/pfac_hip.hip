@@ -783,7 +783,9 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
 }
 
 // Staged words of one tile -> global memory, in order (packed format only: the staged word IS the record).  Four
-// records (16 bytes) per lane per store, aligned to the record array.
+// records (16 bytes) per lane per store, aligned to the record array; non-temporal stores -- the records are not read
+// again by this launch, and written through they do not pile up dirty in L2 until the kernel ends (measured: the same at
+// 1 GiB shards, +3.5 % at 4 GiB).
 __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base, int lane) {
     if (cnt == 0) return;
 #ifdef PFAC_ABL_NOEMIT                         // ablation builds only: records never leave LDS
@@ -804,7 +806,7 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
         for (; i + 8u <= cnt; i += 8u * WAVE) {
             const u32x4 v = {(stage[i] & 0xFFFFu) | (stage[i + 1] << 16), (stage[i + 2] & 0xFFFFu) | (stage[i + 3] << 16),
                              (stage[i + 4] & 0xFFFFu) | (stage[i + 5] << 16), (stage[i + 6] & 0xFFFFu) | (stage[i + 7] << 16)};
-            *reinterpret_cast<u32x4 *>(out + base + i) = v;
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + base + i));
         }
         // the last 1..7 records: one lane each (not a loop in the one lane that stopped there: seven dependent LDS trips)
         const unsigned tail = head + ((cnt - head) & ~7u);
@@ -823,7 +825,7 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
     unsigned i = head + 4u * (unsigned)lane;
     for (; i + 4u <= cnt; i += 4u * WAVE) {
         const u32x4 v = {stage[i], stage[i + 1], stage[i + 2], stage[i + 3]};
-        *reinterpret_cast<u32x4 *>(out + base + i) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + base + i));
     }
     const unsigned tail = head + ((cnt - head) & ~3u);         // the last 1..3 records: one lane each
     if (tail + (unsigned)lane < cnt) out[base + tail + lane] = stage[tail + lane];
