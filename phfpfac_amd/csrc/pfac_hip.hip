@@ -102,7 +102,7 @@ constexpr int L2F_UNROLL = PFAC_L2F_UNROLL;  // survivors classified per trip of
 #endif
 constexpr bool MASK_GATHERS = PFAC_MASK_GATHERS != 0;   // fused walks: exec-mask the table gathers of dead walkers
 #ifndef PFAC_LOAD_AUX
-#define PFAC_LOAD_AUX 0
+#define PFAC_LOAD_AUX 2
 #endif
 constexpr int LOAD_AUX = PFAC_LOAD_AUX;    // cache policy of the tile loads (0 default, 2 = nt: the input is read once)
 constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
