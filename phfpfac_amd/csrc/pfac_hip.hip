@@ -78,12 +78,12 @@ constexpr int MAX_WAVES_PER_BLOCK = 16;     // 15 compute waves + the coordinato
 constexpr int LDS_TOTAL = 160 * 1024;
 constexpr int LDS_TABLE_MAX = 40 * 1024;   // PHF tables up to this size are staged in LDS (variant 0)
 
-// shared (per workgroup) LDS: root row, 8 pre-shifted flag tables (u16: root-edge flag << k | can-be-a-second-byte
-// flag << (k + 8)), then the PHF tables (variant 0)
+// shared (per workgroup) LDS: root row, 4 pre-shifted byte-wide flag tables (root-edge flag << k | can-be-a-second-byte
+// flag << (k + 4), one table per byte of a dword), then the PHF tables (variant 0)
 constexpr int SH_HDR = 0;                  // round rings (H_* below)
 constexpr int SH_S0 = SH_HDR + 2048;
 constexpr int SH_FTAB = SH_S0 + 256 * 4;
-constexpr int SH_D1IDX = SH_FTAB + 8 * 256 * 2; // 256 x u8: dense-row index of the depth-1 state reached on each root byte
+constexpr int SH_D1IDX = SH_FTAB + 4 * 256;  // 256 x u8: dense-row index of the depth-1 state reached on each root byte
 constexpr int SH_FIN = SH_D1IDX + 256;     // 256 x u8: 1 where the depth-1 state reached on that root byte is final
 constexpr int SH_COLMAP = SH_FIN + 256;    // 256 x u8: column of the dense rows a second byte maps to (the last column = no edge)
 constexpr int SH_D1 = SH_COLMAP + 256;     // d1_rows dense rows int32[d1_stride] (the hot first-level transition rows), only the
@@ -833,11 +833,11 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
 
 // Root test: 16-bit mask of the lane's 16 bytes that have an edge out of the root.
 //   ROOT == 1: exactly one such byte value -> exact SWAR compare, flags gathered with v_dot4
-//   ROOT == 0: one LDS lookup per byte in pre-shifted flag tables (table k holds flag << k).  The same lookup
+//   ROOT == 0: one LDS lookup per byte in pre-shifted flag tables (byte k of a dword looks into table k).  The same lookup
 //              answers a second question for free: bits 16..31 of the result = which of the 16 bytes can be the
 //              SECOND byte of a pattern at all (the cheap half of the level-2 filter).
 template <int ROOT>
-__device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned short *ftab, unsigned root_x4) {
+__device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned char *ftab, unsigned root_x4) {
     if (ROOT == 1) {
         unsigned nm[4];
 #pragma unroll
@@ -851,16 +851,23 @@ __device__ __forceinline__ unsigned root_mask(const u32x4 w, const unsigned shor
         hi = __builtin_amdgcn_udot4(nm[3], 0x80402010u, hi, false);
         return ~((lo >> 7) | (hi << 1)) & 0xFFFFu;
     } else {
-        unsigned fa = 0, fb = 0;
+        // four byte-wide tables, one per byte of a dword: table k holds  root flag << k | second-byte flag << (k + 4).
+        // 256 bytes = 64 LDS words = one word per bank, so a wave's 64 random lookups never conflict (the 16-bit
+        // tables, two words per bank, spent half their cycles on conflicts)
+        const unsigned char *t8 = ftab;
+        unsigned p = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const unsigned ba = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            const unsigned bb = (w[2 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
-            fa |= ftab[k * 256 + ba];
-            fb |= ftab[k * 256 + bb];
+        for (int g = 0; g < 4; g++) {
+            const unsigned d = w[g];
+            const unsigned v = (unsigned)t8[d & 0xFFu] | (unsigned)t8[256 + ((d >> 8) & 0xFFu)] |
+                               (unsigned)t8[512 + ((d >> 16) & 0xFFu)] | (unsigned)t8[768 + (d >> 24)];
+            p |= v << (8 * g);
         }
-        // fa: bits 0..7 root flags of bytes 0..7, bits 8..15 their second-byte flags; fb: the same for bytes 8..15
-        return (fa & 0xFFu) | ((fb & 0xFFu) << 8) | ((fa & 0xFF00u) << 8) | ((fb & 0xFF00u) << 16);
+        // p: byte g = dword g's flags, low nibble root, high nibble second-byte -> two 16-bit masks
+        unsigned x = p & 0x0F0F0F0Fu, y = (p >> 4) & 0x0F0F0F0Fu;
+        x = (x | (x >> 4)) & 0x00FF00FFu; y = (y | (y >> 4)) & 0x00FF00FFu;
+        x = (x | (x >> 8)) & 0xFFFFu; y = (y | (y >> 8)) & 0xFFFFu;
+        return x | (y << 16);
     }
 }
 
@@ -885,7 +892,7 @@ template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB>
 __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem, const ErrCh &err) {
     unsigned *hdr = reinterpret_cast<unsigned *>(smem + SH_HDR);
     int *s0 = reinterpret_cast<int *>(smem + SH_S0);
-    unsigned short *ftab = reinterpret_cast<unsigned short *>(smem + SH_FTAB);
+    unsigned char *ftab = smem + SH_FTAB;
     unsigned char *finl = smem + SH_FIN;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -904,7 +911,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         s0[i] = v;
         finl[i] = (unsigned)v < (unsigned)a.num_final ? (unsigned char)1 : (unsigned char)0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) ftab[k * 256 + i] = (unsigned short)((v >= 0 ? 1u << k : 0u) | (sec2 ? 1u << (k + 8) : 0u));
+        for (int k = 0; k < 4; k++)
+            ftab[k * 256 + i] = (unsigned char)((v >= 0 ? 1u << k : 0u) | (sec2 ? 1u << (k + 4) : 0u));
     }
     unsigned char *d1idx_l = smem + SH_D1IDX;
     int *d1_l = reinterpret_cast<int *>(smem + SH_D1);
@@ -1219,7 +1227,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                     // multi-edge root without 1-byte patterns: only survivors whose NEXT byte can be a second byte at
                     // all are looked up (flags of bytes 1..31 from the root test's own lookups, byte 32 = one more)
                     const unsigned nx = *reinterpret_cast<const unsigned *>(tile + off + 32);
-                    const unsigned s32 = (ftab[nx & 0xFFu] >> 8) & 1u;
+                    const unsigned s32 = ((unsigned)ftab[nx & 0xFFu] >> 4) & 1u;
                     cand = m1 & ((((rlo >> 16) | (rhi & 0xFFFF0000u)) >> 1) | (s32 << 31));
                 }
 #ifdef PFAC_ABL_NOCLASS                        // ablation builds only: no survivor is looked up (no records)
