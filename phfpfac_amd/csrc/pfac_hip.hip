@@ -1016,10 +1016,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             const unsigned n_valid = left < (unsigned long long)nc ? (unsigned)left : (unsigned)nc;
             if (!lds_wait_eq(&hdr[H_ARRIVED + (r & 7)], n_valid, err, 4u)) break;
             PFAC_STAMP(trace, 1);
-            const unsigned c = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
+            // (bit 31 of a posted count: that tile is emitted at once and has taken its own space from the heap cursor)
+            const unsigned c_raw = (unsigned)lane < n_valid ? hdr[H_CNT + (r & 7) * 16 + lane] : 0u;
+            const unsigned c_all = c_raw & 0x7FFFFFFFu;
+            const bool self_placed = (c_raw >> 31) != 0u;
+            const unsigned c = self_placed ? 0u : c_all;
             const unsigned incl = wave_incl_scan(c);        // 15 tile counts of < 2^22 each
             const unsigned tot = bcast_last(incl);
             const unsigned excl = incl - c;
+            const unsigned tot_all = __any(self_placed) ? bcast_last(wave_incl_scan(c_all)) : tot;
             // ---- place the tiles (lane c: the tile of compute wave c)
             unsigned long long wb;
             if (tot == 0) {
@@ -1046,7 +1051,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                 ch_used = tot - off;
                 spare = order_chunk();
             }
-            local_total += tot;
+            local_total += tot_all;
             const bool mute = (a.fault & 1u) && blockIdx.x == 1 && r == 1;   // test knob: the bases of this round never come
             if (lane < nc) {
                 hdr[H_WBASE + (r & 7) * 32 + lane * 2] = (unsigned)wb;
@@ -1054,7 +1059,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0 && !mute) lds_store(&hdr[H_READY + (r & 7)], r + 1);
-            if ((unsigned)lane < n_valid) a.tile_index[first + (unsigned)lane] = wb | ((unsigned long long)c << TIX_CNT_SHIFT);
+            if ((unsigned)lane < n_valid && !self_placed) a.tile_index[first + (unsigned)lane] = wb | ((unsigned long long)c << TIX_CNT_SHIFT);
 #ifdef PFAC_TRACE_BUILD
             if (trace) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = g_cur; }
 #endif
@@ -1284,7 +1289,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         if (false)
 #endif
         if (lane == 0) {
-            hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt;
+            hdr[H_CNT + (r & 7) * 16 + wave] = (unsigned)cnt | ((now && cnt != 0) ? 0x80000000u : 0u);
             if (cnt > a.small_cap) {
                 atomicAdd(&hdr[H_OVF2], 1u);
                 if (cnt > a.sparse_cap) atomicAdd(&hdr[H_OVF], 1u);
@@ -1299,15 +1304,22 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         else __builtin_amdgcn_s_setprio(0);
 
         if (now && cnt != 0) {
-            unsigned long long base = 0;
-            if (record_base(r, base)) {
-                if (overflow)
-                    // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
-                    // while its bytes are still in LDS, writing straight to global memory
-                    tile_pass<W8, true, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, base);
-                else
-                    copy_out(a, stage, (unsigned)cnt, base, lane);   // dense mode: staged, emitted at once
-            }
+            // A tile that leaves at once waits for nobody: it takes exactly its records from the heap cursor itself (one
+            // device atomic per tile -- these are the dense tiles, tens of microseconds each) and writes its own index
+            // word; the coordinator only adds its count to the total.
+            unsigned long long v = 0;
+            if (lane == 0)
+                v = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.ctl + CTL_CURSOR), (unsigned long long)cnt,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+                                            __builtin_amdgcn_readfirstlane((unsigned)v);
+            if (lane == 0) a.tile_index[t] = base | ((unsigned long long)cnt << TIX_CNT_SHIFT);
+            if (overflow)
+                // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
+                // while its bytes are still in LDS, writing straight to global memory
+                tile_pass<W8, true, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, base);
+            else
+                copy_out(a, stage, (unsigned)cnt, base, lane);   // dense mode: staged, emitted at once
         }
         if (NB == 2) emit_pending(pend_have[0], pend_cnt[0]);
         PFAC_STAMP(trace, 8);
@@ -2276,7 +2288,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         // chunks of 1024 records get exact allocations (one atomic per batch)
         uint64_t chunk = (capacity / (32 * grid)) & ~3ull;
         if (chunk > (1u << 22)) chunk = 1u << 22;
-        a.chunk = chunk >= 1024 ? (unsigned)chunk : 0u;
+        a.chunk = (chunk >= 1024 && !dense) ? (unsigned)chunk : 0u;      // (dense mode: every tile takes its own space)
         void *kargs[] = {&a};
         // the slot's two events ride on the dispatch itself (start / stop of THIS kernel): no barrier packets of their own
         // in front of and behind every scan
