@@ -2,6 +2,10 @@
 # A/B/n of several builds of the HIP library in ONE gpurun call (same device, interleaved repetitions).
 #   tools/abn.sh build NAME "-DPFAC_X=1 ..."     (here, CPU) compiles the working tree's pfac_hip.hip into ab/lib_NAME.so
 #   tools/abn.sh run "NAME1 NAME2 ..." "workload1 workload2 ..." [reps]      (GPU box; NAME "cur" = the product library)
+# Ablation builds (wrong results on purpose; time them with tools/series.py, which does not check parity):
+#   -DPFAC_ABL_NOROOT (no root test)  -DPFAC_ABL_NOCLASS (no level-2 lookups)  -DPFAC_ABL_NOKEEP (survivors classified, then dropped)
+#   -DPFAC_ABL_NOWALK (deep survivors treated as shallow)  -DPFAC_ABL_NOSTAGE (records counted, never staged)
+#   -DPFAC_ABL_NOEMIT (records never leave LDS)  -DPFAC_ABL_NOLDSCOPY  -DPFAC_ABL_NOCOORD  -DPFAC_ABL_STATIC
 set -e
 cd "$(dirname "$0")/.."
 case "$1" in
