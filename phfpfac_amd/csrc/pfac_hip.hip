@@ -958,6 +958,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         for (int i = tid; i < a.bm2_rows * 8; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();                           // the only workgroup barrier
+#ifdef PFAC_TRACE_BUILD
+    if (a.dbg && blockIdx.x < 8 && threadIdx.x == 0) a.dbg[((size_t)blockIdx.x * 64 + 1) * 32 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
 
 #ifdef PFAC_ABL_NOCOORD                        // ablation builds only: static tiles, no coordinator, counts dropped
     if (wave == nc) return;
@@ -1360,6 +1363,9 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
     static_assert(NW == (TLDS ? 1 : 2) || (FUSED && (NW == 3 || NW == 4)), "walks per lane: 1 (LDS tables), 2 (L2 tables), 3 (L2, fused), 4 (L2, fused, dense matches)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ErrCh err = {&a.ctl[CTL_ERR], a.spin_max};
+#ifdef PFAC_TRACE_BUILD                        // column 15 of a traced workgroup's rows 0 / 1 / 2: entry, tables staged, last wave out
+    if (a.dbg && blockIdx.x < 8 && threadIdx.x == 0) a.dbg[((size_t)blockIdx.x * 64 + 0) * 32 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
     scan_body<TLDS, W8, ROOT, FUSED, NW, NB>(a, smem, err);
     // ---- leaving: the last wave of the workgroup counts the workgroup out; the last workgroup of the grid copies
     // the error flags and the dense-tile count from the control header (device memory) to the host-visible result
@@ -1369,6 +1375,9 @@ __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLO
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's flag atomics have been performed
         const unsigned left = atomicAdd(&hdr[H_EXIT], 1u);
         if (left + 1 == (blockDim.x >> 6)) {
+#ifdef PFAC_TRACE_BUILD
+            if (a.dbg && blockIdx.x < 8) a.dbg[((size_t)blockIdx.x * 64 + 2) * 32 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
             const unsigned done = __hip_atomic_fetch_add(&a.ctl[CTL_DONE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (done + 1 == gridDim.x) {
                 const unsigned long long tot = __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.ctl + CTL_TOTAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -50,6 +50,19 @@ for b in (0, 3):
         per = np.mean(np.diff([x[r, 4] for r in range(4, 60) if x[r, 4]]))
         print("  wave 0 mean phases (us):", {k: round(v / 100, 2) for k, v in ph.items()}, "round", round(per / 100, 2))
 
+# launch skeleton of the 8 traced workgroups: entry -> tables staged -> first tile in LDS ... last wave out
+ent, stg, out_ = d[:, 0, 15], d[:, 1, 15], d[:, 2, 15]
+if ent.any():
+    e0 = ent[ent > 0].min()
+    first_lds = d[:, 0, 5]
+    last_round_end = np.array([max(d[b, r, 8] for r in range(64)) for b in range(8)])
+    n_rounds = [int((d[b, :, 4] > 0).sum()) for b in range(8)]
+    print("launch skeleton (us after the earliest traced entry), workgroups 0..7:")
+    for name, v in (("entry", ent), ("tables staged (after the barrier)", stg), ("first tile of wave 0 in LDS", first_lds),
+                    ("wave 0 done with its last traced round", last_round_end), ("last wave of the workgroup out", out_)):
+        print(f"  {name:42s}", " ".join(f"{(x_ - e0) / 100:8.2f}" if x_ else "    -   " for x_ in v))
+    print("  (rounds traced per workgroup:", n_rounds, "; at most 64)")
+
 acc = d[:, 0, 10:15].sum(axis=0).astype(float)
 if acc[3]:
     print(f"tile_pass of compute wave 0 (8 workgroups, whole launch): {acc[3]:.0f} tiles with FIFO work, {acc[1] / acc[3]:.2f} rounds per tile, "
