@@ -417,6 +417,7 @@ def main():
                    "phf_width": 256, "patterns": res["table"].n_patterns, "states": res["table"].state_num,
                    "kernel_variant": res["info"]["variant"], "tile_bytes": res["info"]["tile_bytes"],
                    "grid_blocks": res["info"]["grid_blocks"], "lds_bytes": res["info"]["lds_bytes"],
+                   "staging_buffers": res["info"]["staging_buffers"], "staging_records": res["info"]["staging_records"],
                    "parallelism": f"input-sharded x{world}, halo {res['table'].halo} B",
                    "matches_per_step": res["matches"], "record_bytes": rec_bytes,
                    "record_layout": "heap of compact records (pos:12 | final state, as wide as the automaton needs) + ordered tile index (8 B per 4 KiB tile)",
