@@ -34,7 +34,7 @@ while time.time() - t0 < seconds:
     for k in ALL: os.environ.pop(k, None)
     os.environ.update(knobs)
     table = PfacTable.from_file(pf, width)
-    n = int(rng.choice([1, 17, 4095, 4097, 70001, 300007]))
+    n = int(rng.choice([1, 17, 4095, 4097, 70001, 300007, 300007, 2_000_003, 9_000_001], p=[.1, .1, .1, .1, .2, .2, .1, .07, .03]))
     data = symbols[rng.integers(0, alpha, n)]
     plist = sorted(pats)
     for at in rng.integers(0, max(n - 1, 1), max(n // 50, 1)):
