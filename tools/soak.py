@@ -63,6 +63,7 @@ with GpuMatcher(0, 2) as g:
     g.reserve(0, 0, N // 2 if "dict" in sys.argv else N // 8)
     g.reserve(1, 0, N // 2 if "dict" in sys.argv else N // 8)
     t0 = time.time()
+    last_note = t0
     scans = 0
     checked = 0
     inflight = []
@@ -96,6 +97,9 @@ with GpuMatcher(0, 2) as g:
                     raise SystemExit(f"RECORD MISMATCH scan {scans}: start {st} n_owned {no} n_avail {na}")
                 checked += 1
         scans += 1
+        if scans % 4096 == 0 and time.time() - last_note > 30:            # (a silent GPU run is taken to be hung)
+            last_note = time.time()
+            print(f"  ... {scans} scans, {time.time() - t0:.0f} s", flush=True)
     for s_, st, no, na in inflight:
         cnt, over = g.scan_finish(s_)
         assert cnt == expected(st, no, na) and not over
