@@ -180,8 +180,6 @@ struct ScanArgs {
     unsigned nbuf;                        // staging buffers per wave: 3 / 2 = emit two / one round(s) later, 1 = emit at once (dense mode)
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation) ...
     unsigned small_cap;                   // ... and than this (the three-buffer capacity) in res[6]
-    unsigned static0, first_ticket;       // static0: workgroup j's first batch is batch j, ticket t of counter c stands for batch
-                                          // (t + first_ticket) * ticket_ways + c  (first_ticket * ticket_ways == gridDim.x); else 0, 0
     unsigned n_tiles;
     unsigned spin_max;             // bound of every spin loop
     unsigned fault;                // test knob (PFAC_FAULT): bit 0 = workgroup 1 never publishes the record bases of its second round
@@ -901,28 +899,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int nc = (int)(blockDim.x >> 6) - 1;             // compute waves; wave nc coordinates
 
-    // prefetch registers: the wave's 4 KiB + halo, LOAD_DEPTH tiles ahead of the one being scanned (set A / set B)
-    u32x4 wA[SUBS], wB[SUBS];
-    u32x4 hA = {0u, 0u, 0u, 0u}, hB = {0u, 0u, 0u, 0u};
-    auto issue_loads = [&](unsigned long long tt, u32x4 (&w)[SUBS], u32x4 &hw) {
-        const unsigned long long tb = tt * WTILE;
-        const unsigned long long remain = a.n_avail - tb;
-        const unsigned lm = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
-        // the descriptor covers whole 16-B units only: every dword of a load is fully inside or reads as 0
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned char *>(a.in + tb), 0, (int)(lm & ~15u), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < SUBS; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, j * SUB + lane * 16, 0, LOAD_AUX);
-        if (lane * 16 < a.halo) hw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, WTILE + lane * 16, 0, 0);
-    };
-    // Round 0's batch is not drawn: workgroup j scans batch j (a.static0; the counters deal the batches from gridDim.x
-    // on).  So a compute wave knows its first tile now, and its loads go out before the tables are staged -- their latency
-    // and the first ticket's round trip run under the prologue instead of behind it.
-    bool early = false;
-    if (a.static0 && wave < nc) {
-        const unsigned long long t0 = (unsigned long long)blockIdx.x * (unsigned)nc + (unsigned)wave;
-        if (t0 < a.n_tiles) { issue_loads(t0, wA, hA); early = true; }
-    }
     // ---- the control header of the slot's NEXT scan (ticket counters, flags, heap cursor of its other buffer) is zeroed here,
     // spread over the whole grid: the next launch on the stream starts after this one has ended
     for (unsigned i = blockIdx.x * blockDim.x + tid; i < a.zero_vec; i += gridDim.x * blockDim.x)
@@ -1000,7 +976,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #else
         auto ticket = [&]() -> unsigned {
             unsigned g = 0;
-            if (lane == 0) g = (atomicAdd(&a.ctl[(blockIdx.x % a.ticket_ways) * 64u], 1u) + a.first_ticket) * a.ticket_ways + blockIdx.x % a.ticket_ways;
+            if (lane == 0) g = atomicAdd(&a.ctl[(blockIdx.x % a.ticket_ways) * 64u], 1u) * a.ticket_ways + blockIdx.x % a.ticket_ways;
             return g;                          // valid in lane 0 (not waited for here)
         };
 #endif
@@ -1015,7 +991,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         };
         unsigned g[AHEAD];                     // batch ids of rounds r .. r+AHEAD-1 (published)
 #pragma unroll
-        for (int k = 0; k < AHEAD; k++) g[k] = publish_batch((unsigned)k, (k == 0 && a.static0) ? blockIdx.x : ticket());
+        for (int k = 0; k < AHEAD; k++) g[k] = publish_batch((unsigned)k, ticket());
         unsigned t_pending = ticket();         // for round AHEAD, published at the top of iteration 0
         // the heap: this workgroup's current chunk [ch_base, ch_base + ch_size), ch_used records of it taken, and the
         // chunk on order (the atomic was issued when the current one came into use; its value sits in lane 0)
@@ -1112,6 +1088,20 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     unsigned *stage0 = reinterpret_cast<unsigned *>(tile + WTILE + a.halo + QCAP * 2);
     const bool root_final = ROOT == 1 && (unsigned)a.root_state < (unsigned)a.num_final;
 
+    // prefetch registers: the wave's 4 KiB + halo, LOAD_DEPTH tiles ahead of the one being scanned (set A / set B)
+    u32x4 wA[SUBS], wB[SUBS];
+    u32x4 hA = {0u, 0u, 0u, 0u}, hB = {0u, 0u, 0u, 0u};
+    auto issue_loads = [&](unsigned long long tt, u32x4 (&w)[SUBS], u32x4 &hw) {
+        const unsigned long long tb = tt * WTILE;
+        const unsigned long long remain = a.n_avail - tb;
+        const unsigned lm = remain < (unsigned long long)(WTILE + a.halo) ? (unsigned)remain : (unsigned)(WTILE + a.halo);
+        // the descriptor covers whole 16-B units only: every dword of a load is fully inside or reads as 0
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char *>(a.in + tb), 0, (int)(lm & ~15u), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < SUBS; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, j * SUB + lane * 16, 0, LOAD_AUX);
+        if (lane * 16 < a.halo) hw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, WTILE + lane * 16, 0, 0);
+    };
     // this wave's tile of round rr; false: there is none (the input is used up) or the ring timed out.
     // Tile numbers are wave-uniform: as scalars they make the buffer descriptor of the tile loads a scalar too
     // (a descriptor in VGPRs costs a readfirstlane "waterfall" loop around every load)
@@ -1138,7 +1128,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     unsigned long long t = 0, t_n1 = 0;        // tiles of rounds r and (LOAD_DEPTH == 2) r+1
     bool have_n1 = false;
     if (!probe(0, t)) return;
-    if (!early) issue_loads(t, wA, hA);
+    issue_loads(t, wA, hA);
     if (LOAD_DEPTH == 2) {
         have_n1 = probe(1, t_n1);
         if (have_n1) issue_loads(t_n1, wB, hB);
@@ -1707,7 +1697,6 @@ struct pfac_ctx {
     unsigned child0 = 0, child1 = 0;
     // tuning / test knobs, read from the environment ONCE, when a table is installed
     unsigned spin_max = SPIN_MAX, fault = 0, ticket_ways_knob = 0;
-    bool no_static0 = false;
     std::string trace_file;
     std::string err;
     std::mutex mu;
@@ -1915,7 +1904,6 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->spin_max = (unsigned)env_int("PFAC_SPIN_MAX", (int)SPIN_MAX);
     if (ctx->spin_max < 64) ctx->spin_max = 64;
     ctx->fault = (unsigned)env_int("PFAC_FAULT", 0);
-    ctx->no_static0 = getenv("PFAC_NO_STATIC0") != nullptr;
     ctx->ticket_ways_knob = (unsigned)env_int("PFAC_TICKET_WAYS", 0);
     ctx->trace_file = getenv("PFAC_TRACE") ? getenv("PFAC_TRACE") : "";
     // The two-buffer layout fixes the number of waves; LDS that no further wave fits into goes to the staging buffers
@@ -2304,8 +2292,6 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         uint64_t grid = (uint64_t)ctx->grid_blocks < want ? (uint64_t)ctx->grid_blocks : want;
         a.ticket_ways = grid < TICKET_WAYS ? (unsigned)grid : TICKET_WAYS;
         if (ctx->ticket_ways_knob >= 1 && ctx->ticket_ways_knob < a.ticket_ways) a.ticket_ways = ctx->ticket_ways_knob;
-        a.static0 = (n_batches >= grid && grid % a.ticket_ways == 0 && !ctx->no_static0) ? 1u : 0u;
-        a.first_ticket = a.static0 ? (unsigned)(grid / a.ticket_ways) : 0u;
         // heap chunk: 1/32 of an even share of the record array per workgroup -- the current and the spare chunk of
         // every workgroup can stay unfilled at the end, i.e. at most 1/16 of the capacity; record arrays too small for
         // chunks of 1024 records get exact allocations (one atomic per batch)
