@@ -186,6 +186,56 @@ def cpu_baseline_pfac(pat_path, kind, para, seconds=6.0):
                       f"over the dense trie (oracle/pfac_oracle.c), records materialised, {n} matches/pass"}
 
 
+def config3_end_to_end(ppath, para, local_rank, chunk=GIB, k_slots=4):
+    """BASELINE configs[2] on one GPU, PCIe INCLUSIVE (reported next to the kernel-resident value, never as it): 4 GiB
+    of the text workload in pinned host memory -> four pipeline slots on four HIP streams (hipMemcpyAsync H2D || scan) ->
+    exact counts.  Everything is enqueued before anything is waited for; the clock runs from the first H2D call to the
+    last count.  The total is checked against the input's period (oracle over a few periods, as the -m gpu test does)."""
+    import numpy as np
+    import torch
+    from orc import Oracle
+    from phfpfac_amd import GpuMatcher, PfacTable
+    from phfpfac_amd.matcher import tiled_bytes
+    table = PfacTable.from_file(ppath, 256)
+    n_total = chunk * k_slots
+    period = len(para)
+    host = torch.empty(chunk + period + table.halo + 64, dtype=torch.uint8).pin_memory()
+    host.numpy()[:] = tiled_bytes(host.numel(), para)
+    hv = host.numpy()
+    o = Oracle(ppath, 1, 1)
+    pos, _ = o.scan_spec(tiled_bytes(period * 8, para), None)
+    per_period = int(((pos >= period) & (pos < 2 * period)).sum())
+    full, tail = divmod(n_total, period)
+    lpos, _ = o.scan_spec(tiled_bytes(tail, para), None)
+    o.close()
+    expect = per_period * full + int(lpos.size)
+    best, counts = None, []
+    with GpuMatcher(local_rank, k_slots) as g:
+        g.load_table(table)
+        for s in range(k_slots):
+            g.reserve(s, chunk + table.halo, chunk // 8)
+        for rep in range(3):                       # first pass warms buffers and clocks; best of the other two
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in range(k_slots):
+                lo = s * chunk
+                n_avail = min(n_total, lo + chunk + table.halo) - lo
+                ph = lo % period
+                g.h2d(hv[ph: ph + n_avail], slot=s)
+                g.scan_async(chunk, n_avail, slot=s)
+            counts = [g.scan_finish(s)[0] for s in range(k_slots)]
+            dt = time.perf_counter() - t0
+            if rep and (best is None or dt < best):
+                best = dt
+        kern = sum(g.elapsed_ms(s) for s in range(k_slots))
+    if sum(counts) != expect:
+        raise SystemExit(f"config-3 end-to-end run: {sum(counts)} matches, expected {expect}")
+    return {"value": round(n_total / best / 1e9, 2), "unit": "GB/s", "bytes": n_total, "ms": round(best * 1e3, 2),
+            "slots": k_slots, "streams": k_slots, "kernel_ms_sum": round(kern, 3), "matches": sum(counts),
+            "note": "PCIe-inclusive (H2D from pinned host memory || scan, counts read back); bound by the host link, "
+                    "reported beside the HBM-resident value, never as it"}
+
+
 def committed_traffic():
     """HBM bytes per headline launch from the committed rocprofv3 --pmc passes -- only when they were taken from this
     very kernel source (tools/summarize_prof.py stores its sha256)."""
@@ -209,6 +259,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true", help="(default at --gpus 1) also time the other workloads (short)")
     ap.add_argument("--no-extra", action="store_true", help="time the named workload only")
+    ap.add_argument("--sustain-seconds", type=float, default=2.5, help="length of the sustained back-to-back run reported beside the K-step value (0: skip)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive config-3 run (4 GiB pinned host -> 4 slots)")
     ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-cores CPU baseline (default: usable cores, at most 32; 0: skip)")
     args = ap.parse_args()
 
@@ -251,6 +303,8 @@ def main():
     per = args.bytes_per_gpu or (GIB if world == 1 else 4 * GIB)
     n_total = per * world
 
+    sustain_s = args.sustain_seconds if world == 1 else min(args.sustain_seconds, 1.0)
+
     def run_workload(name, steps, warmup, headline):
         pat_name, kind, desc = WORKLOADS[name]
         desc = desc.format(size=("%d GiB" % (per >> 30)) if per % GIB == 0 else ("%d bytes" % per))
@@ -278,17 +332,27 @@ def main():
         _, _, used = g.scan_format(0)
         g.reserve(1, 0, max(cap, used + used // 8))
         assert g.scan_resident(n_owned, n_avail, d_input=buf, slot=1) == n
-        # parity spot check (outside the timed region) on the FULL-SIZE launch itself: in (position, length) order the
-        # matches that start in the first 4 MiB are a prefix of the record sequence -- compare that prefix, record for
-        # record, with the CPU oracle run on the same bytes.
-        from orc import Oracle
-        m = min(4 << 20, n_owned)
-        host = buf[: min(n_avail, m + table.halo)].cpu().numpy()
+        # Parity (outside the timed region), on the FULL-SIZE launch itself: the GPU's (match count, order-independent
+        # record checksum) of the WHOLE shard against one serial Aho-Corasick pass (oracle/ac_serial.c, the CHECKER) over
+        # the very bytes the kernel read, copied back from HBM -- every record of the shard enters the comparison.  The
+        # checksum cannot see order, so the records of the first 1 MiB are also compared one by one, in order, with the
+        # oracle's PFAC walk (in (position, length) order they are a prefix of the record sequence).
+        from orc import Oracle, ac_whole_shard
+        chk = g.checksum(n, base=lo, slot=1)
+        host = buf[:n_avail].cpu().numpy()
+        t_par = time.perf_counter()
+        cnt_o, chk_o = ac_whole_shard(ppath, host, n_owned=n_owned, base=lo)
+        t_par = time.perf_counter() - t_par
+        if (n, chk) != (cnt_o, chk_o):
+            raise SystemExit(f"rank {rank}: PARITY FAILURE on workload {name}: GPU (count, checksum) = ({n}, {chk:#x}), "
+                             f"serial Aho-Corasick over the same {n_avail} bytes = ({cnt_o}, {chk_o:#x})")
+        m = min(1 << 20, n_owned)
         o = Oracle(ppath, 1, 1)
-        opos, oids = o.scan_spec(host, None)
+        opos, oids = o.scan_spec(host[: min(n_avail, m + table.halo)], None)
         keep = opos < m
         opos, oids = opos[keep], oids[keep]
         o.close()
+        del host
         k = int(opos.size)
         rec = g.records_to_host(min(n, k + 1), slot=1)
         ok = n >= k and np.array_equal(rec["pos"][:k].astype(np.int64), opos) and \
@@ -370,7 +434,30 @@ def main():
             cnt_all = cnt
         res = {"name": name, "desc": desc, "ppath": ppath, "kind": kind, "dt": dt, "kernel_ms": float(np.mean(kern_ms)),
                "kernel_ms_min": float(np.min(kern_ms)), "matches": cnt_all, "matches_rank": cnt, "table": table,
-               "n_owned": n_owned, "n_avail": n_avail, "settle": settle, "cold_ms": cold_ms}
+               "n_owned": n_owned, "n_avail": n_avail, "settle": settle, "cold_ms": cold_ms, "parity_s": t_par}
+        if headline and sustain_s > 0:
+            # SUSTAINED figure: back-to-back launches for >= sustain_s seconds (thousands of them), every launch timed by
+            # its own HIP event pair -- what a long job sees, next to the K-step value above
+            kern_ms.clear()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t1 < sustain_s:
+                step(k)
+                k += 1
+            drain(exchange=False)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t1
+            gbs = res["n_owned"] / (np.array(kern_ms) * 1e-3) / 1e9
+            res["sustained"] = {"seconds": round(wall, 2), "launches": k,
+                                "kernel_gbs_mean": round(float(res["n_owned"] / (np.mean(kern_ms) * 1e-3) / 1e9), 1),
+                                "kernel_gbs_p5": round(float(np.percentile(gbs, 5)), 1),
+                                "kernel_gbs_p50": round(float(np.percentile(gbs, 50)), 1),
+                                "kernel_gbs_p95": round(float(np.percentile(gbs, 95)), 1),
+                                "wall_gbs": round(res["n_owned"] * k / wall / 1e9, 1),
+                                "frac_of_hbm_peak_mean": round(float(res["n_owned"] / (np.mean(kern_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS), 4),
+                                "note": "back-to-back launches of the same resident shard, each timed by its HIP event pair; "
+                                        "the card's power/clock state over seconds is part of this figure"}
         if headline:
             # What a consumer of ONE ordered record stream pays on top of the scan, reported next to the timed value:
             # heap -> sorted 8-byte records on the device (expand), and (N > 1) their ordered gather on rank 0.
@@ -384,18 +471,30 @@ def main():
             res["expand_ms"] = (time.perf_counter() - t1) * 1e3
             res["heap_used"] = used
             res["n_tiles"] = n_tiles
+            del wide
+            # D2H of the compact form itself (heap words + tile index into pinned host memory): what the CLI's emitter
+            # and any host consumer reads back -- the counterpart of the reference's dense D2H (master_kernel.cu:428)
+            words_h = torch.empty(max(used * rec_b, 1), dtype=torch.uint8).pin_memory()
+            tix_h = torch.empty(max(n_tiles, 1), dtype=torch.int64).pin_memory()
+            for _ in range(2):                               # (first pass: pages the pinned buffers in)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                g.packed_to_host_into(words_h, tix_h, slot=1)
+                res["readback_ms"] = (time.perf_counter() - t1) * 1e3
+            res["readback_bytes"] = used * rec_b + n_tiles * 8
+            del words_h, tix_h
             if use_dist:
-                counts = pdist.gather_counts(cnt, dev)
                 dist.barrier()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                gathered = pdist.gather_records(wide, cnt, counts, dst=0)
+                parts = pdist.gather_packed(g, dev, slot=1, dst=0)          # the COMPACT form travels: 2 B (4 B) per match
                 torch.cuda.synchronize()
                 dist.barrier()
                 res["gather_ms"] = (time.perf_counter() - t1) * 1e3
-                res["gather_records"] = int(sum(counts))
-                del gathered
-            del wide
+                if rank == 0:
+                    res["gather_records"] = sum(p["n_matches"] for p in parts)
+                    res["gather_bytes"] = sum(p["words"].numel() + 8 * p["tix"].numel() for p in parts)
+                del parts
         res["info"] = g.info()
         g.close()
         del buf
@@ -421,10 +520,14 @@ def main():
                    "parallelism": f"input-sharded x{world}, halo {res['table'].halo} B",
                    "matches_per_step": res["matches"], "record_bytes": rec_bytes,
                    "record_layout": "heap of compact records (pos:12 | final state, as wide as the automaton needs) + ordered tile index (8 B per 4 KiB tile)",
-                   "parity": "records of the first 4 MiB per rank == CPU oracle, bit-exact",
+                   "parity": "whole shard: count + checksum == serial AC (every rank, over the bytes copied back from HBM); "
+                             "records of the first 1 MiB == CPU oracle in order, bit-exact",
                    "settle_launches": res["settle"], "cold_first20_gbs": round(res["n_owned"] / (res["cold_ms"] * 1e-3) / 1e9, 1),
+                   "value_note": "steady state, best plateau: K steps after the clock-settling launches; `sustained` is the same scan run back to back for seconds",
                    "expand_ms": round(res["expand_ms"], 3),
                    "expand_note": "heap -> one sorted pfac_record array on the device, outside the timed region (what an ordered consumer pays)",
+                   "readback_ms": round(res["readback_ms"], 3), "readback_bytes": res["readback_bytes"],
+                   "readback_note": "D2H of the compact form (record heap + tile index) into pinned host memory, outside the timed region (the reference's dense D2H, master_kernel.cu:428, made compact)",
                    "multi_gpu_note": "N > 1 numbers exist only where the driver ran them (SCALE_rNN.json): the builder's box has one GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
@@ -434,9 +537,12 @@ def main():
                      "kernel_ms_min": round(res["kernel_ms_min"], 4),
                      "algorithmic_bytes_per_launch": res["n_owned"]},
     }
+    if "sustained" in res:
+        out["sustained"] = res["sustained"]
     if "gather_ms" in res:
         out["config"]["gather_ms"] = round(res["gather_ms"], 3)
-        out["config"]["gather_note"] = f"ordered gather of {res['gather_records']} 8-byte records to rank 0 (send/recv over RCCL), outside the timed region"
+        out["config"]["gather_note"] = (f"ordered gather of {res.get('gather_records')} records to rank 0 in the COMPACT form the scan "
+                                        f"wrote ({res.get('gather_bytes')} bytes: heap words + tile index, send/recv over RCCL), outside the timed region")
     if world == 1 and not args.no_extra:
         out["other_workloads"] = {}
         for name in sorted(WORKLOADS):
@@ -449,6 +555,8 @@ def main():
                 "kernel_gbs": round(r["n_owned"] / (r["kernel_ms"] * 1e-3) / 1e9, 2),
                 "frac_of_hbm_peak": round(r["n_owned"] / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "steps": k, "matches_per_step": r["matches"], "kernel_variant": r["info"]["variant"]}
+    if world == 1 and not args.no_end_to_end and args.workload == HEADLINE:
+        out["end_to_end"] = config3_end_to_end(res["ppath"], para, local_rank)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(res["ppath"], res["kind"], para)
         out["cpu_baseline_pfac"] = cpu_baseline_pfac(res["ppath"], res["kind"], para)

@@ -170,9 +170,11 @@ int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uin
                              int n_threads);
 /* The same text straight from the compact device form (record heap + tile index as pfac_records_d2h_packed
  * delivers them), tiles in order: position = base + t * 4096 + PFAC_PACKED_POS(word), pattern =
- * idmap[PFAC_PACKED_STATE(word)]; record_bytes = 2 or 4 as pfac_scan_format reports.  n_threads < 2: serial. */
-int64_t pfac_emit_packed(void *file, const void *words, int record_bytes, const uint64_t *tile_index, uint64_t n_tiles,
-                         uint64_t base, const int32_t *idmap, int n_threads);
+ * idmap[PFAC_PACKED_STATE(word)]; record_bytes = 2 or 4 and n_words = heap words held by `words` (*used), as
+ * pfac_scan_format reports.  A tile whose records would lie outside words[0, n_words) -> PFAC_E_ARG, nothing written.
+ * n_threads < 2: serial. */
+int64_t pfac_emit_packed(void *file, const void *words, uint64_t n_words, int record_bytes, const uint64_t *tile_index,
+                         uint64_t n_tiles, uint64_t base, const int32_t *idmap, int n_threads);
 /* Merge of per-partition match lists, replaces main.cc:304-324.  lists[k] (counts[k] records, sorted by
  * position as the scan emits them) comes from partition k of pfac_table_build_file_part(); the result is
  * ordered by (position, partition) -- i.e. by (position, pattern length), the reference's output order -- and
@@ -262,6 +264,13 @@ int pfac_records_expand(pfac_ctx *ctx, int slot, const void *d_records, uint64_t
  * from it).  PFAC_E_STATE when the last scan was not compact. */
 int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, void *host_words, uint64_t n_words,
                             uint64_t *host_tile_index);
+
+/* The compact form handed to a consumer that STAYS ON THE DEVICE (the RCCL record gather sends it: 2 or 4 bytes per
+ * match plus 8 bytes per 4 KiB tile over xGMI instead of 8-byte pfac_records): the n_tiles entries of the slot's tile
+ * index -> d_tile_index_out and, unless d_words_out is NULL or the record heap itself, heap words [0, n_words) ->
+ * d_words_out (device pointers; n_words = *used of pfac_scan_format).  Asynchronous on the slot's stream. */
+int pfac_records_packed_device(pfac_ctx *ctx, int slot, const void *d_records, void *d_words_out, uint64_t n_words,
+                               uint64_t *d_tile_index_out);
 
 /* Order-independent 64-bit checksum of ALL records of the slot's last scan (sum over records of
  * mix(base+pos, idmap[state])), computed on the GPU; used for full-size parity checks where materialising

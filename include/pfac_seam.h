@@ -3,8 +3,9 @@
  *
  * regex_GPU_PHF/main.cc:19-37 declares struct thread_data and three free functions with C++ linkage
  * (defined in master_kernel.cu:188-257, 277-455, 457-524).  libpfac_seam.so (phfpfac_amd/csrc/pfac_seam.cc) defines
- * the same three functions, same parameter lists (the cudaStream_t becomes a void* -- the reference never uses it,
- * master_kernel.cu:277,406,425), on top of the C-ABI of pfac.h: a maintainer keeps main.cc, drops master_kernel.cu
+ * the same three functions, same parameter lists (the cudaStream_t, which the reference never uses --
+ * master_kernel.cu:277,406,425 -- is accepted both as a void* and as a hipStream_t: two overloads), on top of the
+ * C-ABI of pfac.h: a maintainer keeps main.cc, drops master_kernel.cu
  * and links this library instead.  C++ only (struct by value, mangled names), exactly like the reference.
  *
  * Behaviour kept: the device is the caller's CURRENT device (main.cc calls cudaSetDevice before each of them,
@@ -33,11 +34,16 @@ struct thread_data {            /* main.cc:19-32, field for field */
 };
 
 typedef void *pfac_seam_stream;  /* where main.cc passes a cudaStream_t */
+struct ihipStream_t;             /* hipStream_t == ihipStream_t * (hip/hip_runtime_api.h): what a hipified main.cc:36 names */
 
 int GPU_Malloc_Memory(thread_data dataset, unsigned char **d_input_string, int **d_r, int **d_hash_table,
                       unsigned int **d_match_result, int **d_val_table, int **d_s0Table);             /* main.cc:35 */
 int GPU_TraceTable(thread_data dataset, pfac_seam_stream stream, unsigned char *d_input_string, int *d_r,
                    int *d_hash_table, unsigned int *d_match_result, int *d_val_table, int *d_s0Table);  /* main.cc:36 */
+/* The same function for a main.cc whose cudaStream_t became hipStream_t (its prototype at main.cc:36 then mangles to
+ * ...P12ihipStream_t...): such a main.cc links against this library with NO typedef and no edit of the prototype. */
+int GPU_TraceTable(thread_data dataset, ihipStream_t *stream, unsigned char *d_input_string, int *d_r,
+                   int *d_hash_table, unsigned int *d_match_result, int *d_val_table, int *d_s0Table);
 int GPU_Free_memory(unsigned char **d_input_string, int **d_r, int **d_hash_table, unsigned int **d_match_result,
                     int **d_val_table, int **d_s0Table);                                               /* main.cc:37 */
 

@@ -111,6 +111,34 @@ int64_t ac_scan_count(const ac_model *a, const unsigned char *in, int64_t N, uin
     return cnt;
 }
 
+/* The same count over a SLICE of a larger buffer, so that a whole 1-4 GiB shard can be checked on several host threads:
+ * the automaton starts cold at in[0]; only hits that END at byte >= first_end and START before start_limit are counted,
+ * hashed at position base + start.  With in = shard + a - (L-1) (L = longest pattern), first_end = L-1 (clamped at
+ * the shard's head) and N covering up to byte b, the slices' (count, checksum) sums equal one serial pass over the
+ * shard: a hit ending at e >= a starts at >= a - (L-1), which is where the cold automaton started.  start_limit is
+ * the GPU scan's n_owned (matches are keyed by START offset, master_kernel.cu:37-74; the bytes behind n_owned are
+ * read-only halo). */
+int64_t ac_scan_count_range(const ac_model *a, const unsigned char *in, int64_t N, int64_t first_end, int64_t start_limit,
+                            uint64_t base, uint64_t *checksum) {
+    const int32_t *next = a->next, *out_id = a->out_id, *out_len = a->out_len, *dict = a->dict;
+    int s = 0;
+    int64_t cnt = 0;
+    uint64_t sum = 0;
+    for (int64_t e = 0; e < N; e++) {
+        s = next[(size_t)s * 256 + in[e]];
+        if ((out_id[s] | dict[s]) && e >= first_end) {
+            for (int t = out_id[s] ? s : dict[s]; t; t = dict[t]) {
+                const int64_t st = e - out_len[t] + 1;
+                if (st >= start_limit) continue;
+                sum += match_hash(base + (uint64_t)st, (uint32_t)out_id[t]);
+                cnt++;
+            }
+        }
+    }
+    if (checksum) *checksum = sum;
+    return cnt;
+}
+
 /* Collect (start, id); order is end-major (AC order), callers compare as a set. */
 int64_t ac_scan_collect(const ac_model *a, const unsigned char *in, int64_t N, orc_matches *out) {
     int s = 0;

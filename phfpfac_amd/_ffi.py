@@ -82,7 +82,7 @@ HIP_SYMBOLS = (
     "pfac_slot_records", "pfac_slot_stream", "pfac_slot_set_stream", "pfac_slot_h2d", "pfac_scan_async",
     "pfac_scan_finish", "pfac_scan_elapsed_ms", "pfac_records_d2h", "pfac_slot_sync", "pfac_records_checksum",
     "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_scan_staging", "pfac_trace_table_compat", "pfac_scan_format",
-    "pfac_records_expand", "pfac_records_d2h_packed", "pfac_scan_capacity_hint",
+    "pfac_records_expand", "pfac_records_d2h_packed", "pfac_scan_capacity_hint", "pfac_records_packed_device",
 )
 
 _host = None
@@ -120,7 +120,7 @@ def host_lib() -> C.CDLL:
         L.pfac_emit_records.restype = C.c_int64
         L.pfac_emit_records_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.pfac_emit_records_mt.restype = C.c_int64
-        L.pfac_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        L.pfac_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.pfac_emit_packed.restype = C.c_int64
         OP = C.POINTER(COutputs)
         L.pfac_table_build_file_charclass.argtypes = [C.c_char_p, C.c_int, C.POINTER(TP), C.POINTER(OP), C.c_char_p, C.c_size_t]
@@ -179,6 +179,7 @@ def hip_lib() -> C.CDLL:
         L.pfac_scan_capacity_hint.argtypes = [vp, i, C.POINTER(u64)]
         L.pfac_records_expand.argtypes = [vp, i, vp, u64, u64, vp]
         L.pfac_records_d2h_packed.argtypes = [vp, i, vp, vp, u64, vp]
+        L.pfac_records_packed_device.argtypes = [vp, i, vp, vp, u64, vp]
         L.pfac_slot_sync.argtypes = [vp, i]
         L.pfac_records_checksum.argtypes = [vp, i, vp, u64, u64, C.POINTER(u64)]
         L.pfac_fill_tiled.argtypes = [vp, i, vp, u64, vp, C.c_uint32, u64]

@@ -27,7 +27,9 @@
  *     while later ones are still being scanned, so memory stays bounded.
  * There is no CPU matching path in this program: without a GPU it fails.
  *
- * Environment: PFAC_GPUS=n limits the number of GPUs used; PFAC_CHUNK_MB sets
+ * Environment: PFAC_GPUS=n limits the number of GPUs used; PFAC_WORKERS_PER_GPU=m runs m independent workers (host
+ * thread + context + pipeline slots each) on every GPU -- the chunks are dealt round-robin over all n * m workers, so the
+ * multi-worker dealing and the shared in-order emitter can be exercised on a single device; PFAC_CHUNK_MB sets
  * the chunk size (default 64); PFAC_EMIT_THREADS the emitter's formatter threads;
  * PFAC_READ_THREADS the threads that pread() one chunk (default: cores / GPUs, at most 8).
  */
@@ -51,12 +53,13 @@ typedef struct {
     int word_bytes;
     uint64_t *tix;
     uint64_t n_tiles;
+    uint64_t n_words;       /* heap words copied back (pfac_scan_format's *used) */
     uint64_t n_rec;
     int done;               /* guarded by g_mu */
 } chunk_t;
 
 typedef struct {
-    int device, n_gpu, n_streams;
+    int index, device, n_gpu, n_streams;    /* worker `index` of n_gpu workers (the name is historical: workers, not devices), on GPU `device` */
     const int32_t *blob;
     size_t blob_words;
     int fd;                         /* input file */
@@ -65,6 +68,7 @@ typedef struct {
     int n_chunks;
     int read_threads;               /* threads that pread() one chunk into the pinned staging buffer */
     double kernel_ms, setup_ms, read_ms, drain_ms;   /* where this worker's wall time went */
+    int internal_retries;           /* scans repeated after PFAC_E_INTERNAL (a protocol timeout: a bug, reported, never hidden) */
     int rc;
     char err[256];
 } worker_t;
@@ -82,7 +86,7 @@ static double now_ms(void) {
 }
 
 static int fail(worker_t *w, pfac_ctx *ctx, int rc, const char *what) {
-    snprintf(w->err, sizeof w->err, "GPU %d: %s: %s", w->device, what, ctx ? pfac_last_error(ctx) : "");
+    snprintf(w->err, sizeof w->err, "worker %d (GPU %d): %s: %s", w->index, w->device, what, ctx ? pfac_last_error(ctx) : "");
     w->rc = rc;
     pthread_mutex_lock(&g_mu);
     g_failed = 1;
@@ -139,11 +143,17 @@ static int read_parallel(int fd, void *dst, uint64_t n, uint64_t off, int n_thre
 static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap) {
     uint64_t n = 0;
     int rc = pfac_scan_finish(ctx, slot, &n);
-    /* a record heap that was too small is grown and the chunk (still in the slot's input buffer) scanned again; a
-     * protocol timeout (PFAC_E_INTERNAL: e.g. another kernel held the CUs this scan's workgroups needed) gets one retry */
+    /* a record heap that was too small is grown and the chunk (still in the slot's input buffer) scanned again.  A
+     * protocol timeout (PFAC_E_INTERNAL) gets ONE retry so that a long job is not lost -- but every bounded wait of the
+     * kernel is inside one workgroup, so a timeout is a defect, not contention: it is printed when it happens and counted
+     * in the summary, never swallowed */
     for (int attempt = 0, retried = 0; (rc == PFAC_E_OVERFLOW && attempt < 4) || (rc == PFAC_E_INTERNAL && !retried); attempt++) {
-        if (rc == PFAC_E_INTERNAL) retried = 1;
-        else {
+        if (rc == PFAC_E_INTERNAL) {
+            retried = 1;
+            w->internal_retries++;
+            fprintf(stderr, "gphf: GPU %d: chunk at offset %llu: %s -- scanning it once more\n", w->device,
+                    (unsigned long long)c->base, pfac_last_error(ctx));
+        } else {
             uint64_t hint = 0;
             if ((rc = pfac_scan_capacity_hint(ctx, slot, &hint))) return fail(w, ctx, rc, "capacity hint");
             *cap = hint > 2 * *cap ? hint : 2 * *cap;
@@ -161,6 +171,7 @@ static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap
     if ((rc = pfac_scan_format(ctx, slot, &rec_bytes, &c->n_tiles, &used))) return fail(w, ctx, rc, "format");
     if (rec_bytes < 8) {                            /* 2 or 4 bytes per match over PCIe; the emitter prints from this form */
         c->word_bytes = rec_bytes;
+        c->n_words = used;
         c->words = malloc((used ? used : 1) * (size_t)rec_bytes);
         c->tix = (uint64_t *)malloc((c->n_tiles ? c->n_tiles : 1) * sizeof(uint64_t));
         if (!c->words || !c->tix) return fail(w, NULL, PFAC_E_NOMEM, "out of host memory for records");
@@ -203,7 +214,7 @@ static void *worker(void *arg) {
         if ((rc = pfac_slot_reserve(ctx, s, w->chunk_bytes + w->halo, cap[s]))) { fail(w, ctx, rc, "reserve"); goto out; }
     }
     w->setup_ms = now_ms() - ts;
-    for (int j = 0, k = w->device; k < w->n_chunks && !w->rc; j++, k += w->n_gpu) {
+    for (int j = 0, k = w->index; k < w->n_chunks && !w->rc; j++, k += w->n_gpu) {
         const int slot = j % w->n_streams;
         chunk_t *c = &w->chunks[k];
         const double td = now_ms();
@@ -270,6 +281,9 @@ int main(int argc, char *argv[]) {
     if ((rc = pfac_device_count(&n_gpu)) || n_gpu < 1) { fprintf(stderr, "no GPU available: %s\n", pfac_last_error(NULL)); return 1; }
     const char *lim = getenv("PFAC_GPUS");
     if (lim && atoi(lim) > 0 && atoi(lim) < n_gpu) n_gpu = atoi(lim);
+    const int n_dev = n_gpu;
+    const char *wpg = getenv("PFAC_WORKERS_PER_GPU");
+    if (wpg && atoi(wpg) > 1 && atoi(wpg) <= 8) n_gpu *= atoi(wpg);      /* from here on n_gpu counts WORKERS */
     uint64_t chunk = 64ull << 20;       /* small enough that pinning the staging buffers stays cheap, large enough to fill the GPU */
     const char *cm = getenv("PFAC_CHUNK_MB");
     if (cm && atoll(cm) > 0) chunk = (uint64_t)atoll(cm) << 20;
@@ -304,7 +318,7 @@ int main(int argc, char *argv[]) {
     pthread_t *th = (pthread_t *)malloc((size_t)n_gpu * sizeof(pthread_t));
     for (int g = 0; g < n_gpu; g++) {                            /* one host thread per GPU, main.cc:180-241 */
         worker_t *w = &ws[g];
-        w->device = g; w->n_gpu = n_gpu; w->n_streams = streamnum; w->blob = blob; w->blob_words = words;
+        w->index = g; w->device = g % n_dev; w->n_gpu = n_gpu; w->n_streams = streamnum; w->blob = blob; w->blob_words = words;
         w->fd = fd; w->chunk_bytes = chunk; w->halo = halo; w->chunks = chunks; w->n_chunks = n_chunks; w->read_threads = read_threads;
         pthread_create(&th[g], NULL, worker, w);
     }
@@ -320,7 +334,7 @@ int main(int argc, char *argv[]) {
         if (!ok) break;
         double e0 = now_ms();
         const int64_t wrote = chunks[k].words
-            ? pfac_emit_packed(fpout, chunks[k].words, chunks[k].word_bytes, chunks[k].tix, chunks[k].n_tiles, chunks[k].base, tab->idmap, emit_threads)
+            ? pfac_emit_packed(fpout, chunks[k].words, chunks[k].n_words, chunks[k].word_bytes, chunks[k].tix, chunks[k].n_tiles, chunks[k].base, tab->idmap, emit_threads)
             : pfac_emit_records_mt(fpout, chunks[k].rec, chunks[k].n_rec, chunks[k].base, tab->idmap, emit_threads);
         if (wrote < 0) {
             fprintf(stderr, "write failed\n");
@@ -348,14 +362,17 @@ int main(int argc, char *argv[]) {
     if (emit_failed) return 1;
     printf("/////////////////////////////////////////////\n");
     printf("1.Time for  create PFAC + Hashtable : %lf seconds\n", (t1 - t0) / 1e3);
-    printf("2.Time for  %d GPU match progress (read + H2D + kernel + D2H + emit, %d stream(s) each): %lf mseconds (%.3f GB/s end to end)\n",
-           n_gpu, streamnum, t3 - t2, t3 > t2 ? (double)N / (t3 - t2) / 1e6 : 0.0);
+    printf("2.Time for  %d GPU match progress (%d worker(s); read + H2D + kernel + D2H + emit, %d stream(s) each): %lf mseconds (%.3f GB/s end to end)\n",
+           n_dev < n_gpu ? n_dev : n_gpu, n_gpu, streamnum, t3 - t2, t3 > t2 ? (double)N / (t3 - t2) / 1e6 : 0.0);
     printf("3.Kernel time summed over chunks: %lf mseconds (%.3f GB/s kernel-resident per GPU)\n", kernel_ms,
            kernel_ms > 0 ? (double)N / kernel_ms / 1e6 : 0.0);
     printf("4.Time for  emit %llu matches (overlapped with the scan): %lf mseconds\n", (unsigned long long)total, emit_ms);
+    int retries = 0;
+    for (int g = 0; g < n_gpu; g++) retries += ws[g].internal_retries;
+    if (retries) printf("!! %d scan(s) were repeated after a kernel protocol timeout (PFAC_E_INTERNAL, see stderr): please report\n", retries);
     for (int g = 0; g < n_gpu; g++)
-        printf("5.GPU %d host thread: setup (context, table, pinned staging) %.1f ms, file read %.1f ms (%d threads), waiting for scans/readback %.1f ms\n",
-               g, ws[g].setup_ms, ws[g].read_ms, read_threads, ws[g].drain_ms);
+        printf("5.worker %d (GPU %d) host thread: setup (context, table, pinned staging) %.1f ms, file read %.1f ms (%d threads), waiting for scans/readback %.1f ms\n",
+               g, ws[g].device, ws[g].setup_ms, ws[g].read_ms, read_threads, ws[g].drain_ms);
     printf("matching process finshed\n");
     printf("/////////////////////////////////////////////\n");
     close(fd);

@@ -2373,6 +2373,11 @@ int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms) {
 // Records [first, first+n) of the slot's last scan, in (position, pattern length) order -> pfac_record at d_out
 // (device), on the slot's stream: prefix over the tile index, then a copy out of the heap.
 static int expand_records(pfac_ctx *ctx, Slot &s, const void *src, uint64_t first, uint64_t n, pfac_record *d_out) {
+    // records that do not exist, or that the last scan could not write, are never delivered as if they did: the copy
+    // kernel skips them and the caller would read whatever its buffer held before
+    if (s.pending) return fail(ctx, PFAC_E_STATE, "records requested before pfac_scan_finish");
+    if (first + n > s.last_total) return fail(ctx, PFAC_E_ARG, "records [first, first + n) exceed the scan's match count");
+    if (s.last_used > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "the slot's last scan overflowed its record heap: scan again with a larger one");
     if (n == 0 || s.last_tiles == 0) return PFAC_OK;
     const unsigned n_groups = (unsigned)((s.last_tiles + XGROUP - 1) / XGROUP);
     if (n_groups > s.gsum_cap) {
@@ -2458,6 +2463,23 @@ int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, void
     USE_DEVICE(ctx);
     if (n_words) HIP_TRY(ctx, hipMemcpyAsync(host_words, src, n_words * (uint64_t)s.last_rec_bytes, hipMemcpyDeviceToHost, s.stream));
     if (s.last_tiles) HIP_TRY(ctx, hipMemcpyAsync(host_tile_index, s.d_tile_index, s.last_tiles * 8, hipMemcpyDeviceToHost, s.stream));
+    return PFAC_OK;
+}
+
+int pfac_records_packed_device(pfac_ctx *ctx, int slot, const void *d_records, void *d_words_out, uint64_t n_words,
+                               uint64_t *d_tile_index_out) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    Slot &s = ctx->slots[slot];
+    const void *src = d_records ? d_records : s.d_records;
+    if (!s.scanned || s.pending || s.last_rec_bytes == 8) return fail(ctx, PFAC_E_STATE, "pfac_records_packed_device: the slot's last finished scan did not produce compact records");
+    if (s.last_used > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "the slot's last scan overflowed its record heap: scan again with a larger one");
+    if (!d_tile_index_out || (d_words_out && !src)) return fail(ctx, PFAC_E_ARG, "pfac_records_packed_device: null buffer");
+    if (n_words > s.last_cap) return fail(ctx, PFAC_E_ARG, "pfac_records_packed_device: more words than the record array holds");
+    USE_DEVICE(ctx);
+    if (d_words_out && n_words && d_words_out != src)
+        HIP_TRY(ctx, hipMemcpyAsync(d_words_out, src, n_words * (uint64_t)s.last_rec_bytes, hipMemcpyDeviceToDevice, s.stream));
+    if (s.last_tiles) HIP_TRY(ctx, hipMemcpyAsync(d_tile_index_out, s.d_tile_index, s.last_tiles * 8, hipMemcpyDeviceToDevice, s.stream));
     return PFAC_OK;
 }
 

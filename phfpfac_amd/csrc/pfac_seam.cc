@@ -86,6 +86,13 @@ int GPU_TraceTable(thread_data dataset, pfac_seam_stream /*unused, as in the ref
     return 0;
 }
 
+// the overload a hipified main.cc:36 references (cudaStream_t -> hipStream_t); the stream stays unused
+int GPU_TraceTable(thread_data dataset, ihipStream_t *, unsigned char *d_input_string, int *d_r, int *d_hash_table,
+                   unsigned int *d_match_result, int *d_val_table, int *d_s0Table) {
+    return GPU_TraceTable(dataset, static_cast<pfac_seam_stream>(nullptr), d_input_string, d_r, d_hash_table, d_match_result,
+                          d_val_table, d_s0Table);
+}
+
 // master_kernel.cu:457-524
 int GPU_Free_memory(unsigned char **d_input_string, int **d_r, int **d_hash_table, unsigned int **d_match_result,
                     int **d_val_table, int **d_s0Table) {

@@ -837,15 +837,22 @@ int64_t pfac_emit_records_mt(void *file, const pfac_record *rec, uint64_t n, uin
     return emit_mt((FILE *)file, &s, n, base, idmap, n_threads);
 }
 
-int64_t pfac_emit_packed(void *file, const void *words, int record_bytes, const uint64_t *tile_index, uint64_t n_tiles,
-                         uint64_t base, const int32_t *idmap, int n_threads) {
+int64_t pfac_emit_packed(void *file, const void *words, uint64_t n_words, int record_bytes, const uint64_t *tile_index,
+                         uint64_t n_tiles, uint64_t base, const int32_t *idmap, int n_threads) {
     if (!file || (!tile_index && n_tiles) || (record_bytes != 2 && record_bytes != 4)) return PFAC_E_ARG;
     uint64_t *pre = (uint64_t *)malloc((size_t)(n_tiles + 1) * sizeof(uint64_t));
     if (!pre) return PFAC_E_NOMEM;
     uint64_t n = 0;
-    for (uint64_t t = 0; t < n_tiles; t++) { pre[t] = n; n += PFAC_TIX_COUNT(tile_index[t]); }
-    pre[n_tiles] = n;
     int64_t rc = PFAC_E_ARG;
+    /* the tile index comes from the device: an index copied after an overflowed or failed scan, or paired with a
+     * shorter heap copy, must not send the formatter outside words[0, n_words) */
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        const uint64_t cnt = PFAC_TIX_COUNT(tile_index[t]);
+        if (cnt && PFAC_TIX_FIRST(tile_index[t]) + cnt > n_words) { free(pre); return PFAC_E_ARG; }
+        pre[t] = n;
+        n += cnt;
+    }
+    pre[n_tiles] = n;
     if (words || !n) {
         const rec_src s = {NULL, words, record_bytes, tile_index, pre, n_tiles};
         rc = emit_mt((FILE *)file, &s, n, base, idmap, n_threads);

@@ -64,7 +64,7 @@ int main(int argc, char *argv[]) {
         d.val = tab[p]->val;
         unsigned char *d_input_string; int *d_r, *d_hash_table, *d_val_table, *d_s0Table; unsigned int *d_match_result;
         GPU_Malloc_Memory(d, &d_input_string, &d_r, &d_hash_table, &d_match_result, &d_val_table, &d_s0Table);
-        GPU_TraceTable(d, nullptr, d_input_string, d_r, d_hash_table, d_match_result, d_val_table, d_s0Table);
+        GPU_TraceTable(d, (hipStream_t)nullptr, d_input_string, d_r, d_hash_table, d_match_result, d_val_table, d_s0Table);
         GPU_Free_memory(&d_input_string, &d_r, &d_hash_table, &d_match_result, &d_val_table, &d_s0Table);
     }
     // merge, position-major: chunk p's ids go behind what position i already holds (main.cc:304-324) ...

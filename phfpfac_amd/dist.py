@@ -10,7 +10,9 @@ read-only tables, so shards are independent units:
 * the packed table image is broadcast ONCE from rank 0 (``broadcast_table``);
 * per scan the only exchange is an all-gather of one match count per rank (``gather_counts``), which
   gives every rank its record offset; records are gathered to one rank only when a single ordered
-  stream is wanted (``gather_records``) -- rank order == position order, so concatenation is sorted.
+  stream is wanted -- in the COMPACT form the scan wrote (``gather_packed``: 2 or 4 bytes per match + 8 bytes per
+  4 KiB tile; rank order == position order and each rank's tile index is ordered, so the parts print or expand
+  in sequence), or as expanded 8-byte records (``expanded_records`` + ``gather_records``).
 
 No data-path collective touches the input bytes.
 
@@ -96,12 +98,14 @@ def gather_counts_async(n_local: int, device: torch.device):
 
 
 def gather_records(records: torch.Tensor, n_local: int, counts: List[int], dst: int = 0) -> Optional[torch.Tensor]:
-    """Ordered gather of compact records to rank ``dst``.
+    """Ordered gather of EXPANDED records to rank ``dst`` (8 bytes per match; prefer ``gather_packed``, which moves the
+    compact form -- a quarter of the bytes for a 16-bit automaton).
 
-    ``records`` is this rank's record buffer viewed as int64 (one 8-byte ``pfac_record`` per element,
-    at least ``n_local`` long).  Returns, on ``dst``, one int64 tensor of ``sum(counts)`` records in rank
-    (== position) order; ``None`` elsewhere.  Positions stay shard-relative: add ``shard_range(...)[0]``
-    of the owning rank (``split_gathered``).
+    ``records`` must hold this rank's SORTED 8-byte ``pfac_record``s viewed as int64, at least ``n_local`` of them:
+    the output of ``GpuMatcher.expand_records`` (``pfac_records_expand``) -- NOT the slot's record buffer, which is the
+    unordered heap of 2- or 4-byte compact words (``pfac.h``); ``expanded_records`` below does the expansion.
+    Returns, on ``dst``, one int64 tensor of ``sum(counts)`` records in rank (== position) order; ``None`` elsewhere.
+    Positions stay shard-relative: add ``shard_range(...)[0]`` of the owning rank (``split_gathered``).
     """
     rank, world = dist.get_rank(), dist.get_world_size()
     if rank == dst:
@@ -122,6 +126,124 @@ def gather_records(records: torch.Tensor, n_local: int, counts: List[int], dst: 
     if n_local:
         dist.send(records[:n_local].contiguous(), dst=dst)
     return None
+
+
+def expanded_records(matcher, n_local: int, device: torch.device, slot: int = 0, d_records=None) -> torch.Tensor:
+    """This rank's records of the slot's last scan as ``gather_records`` wants them: sorted 8-byte ``pfac_record``s in
+    a fresh int64 tensor on ``device`` (``pfac_records_expand``; the slot's stream is synchronised)."""
+    wide = torch.empty(max(int(n_local), 1), dtype=torch.int64, device=device)
+    if n_local:
+        matcher.expand_records(int(n_local), wide, slot=slot, d_records=d_records)
+    matcher.sync(slot)
+    return wide
+
+
+# ---------------------------------------------------------------------------
+# the compact gather: what the scan wrote is what travels
+
+def gather_packed_tensors(words: torch.Tensor, tile_index: torch.Tensor, rec_bytes: int, n_matches: int, dst: int = 0):
+    """Ordered gather of the COMPACT record form to rank ``dst``: every rank passes its record heap as a uint8 tensor
+    (``used * rec_bytes`` bytes: 2- or 4-byte words ``pos_in_tile:12 | final state``) and its tile index (int64, one
+    ``first | count << 40`` entry per 4 KiB tile -- the index is what is ordered, ``pfac.h``).  One all-gather of four
+    int64 per rank (bytes, tiles, record width, matches), then one send per tensor per rank to ``dst``.
+    Returns on ``dst`` a list with one dict per rank, in rank (== position) order:
+    ``{"words": uint8 tensor, "tix": int64 tensor, "rec_bytes": int, "n_matches": int}``; ``None`` elsewhere.
+    ``pfac_emit_packed`` prints a rank's part as it is (``emit_gathered``); ``packed_to_records`` expands it.
+    Works on CPU tensors with gloo as well (tests/test_dist_cpu.py)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = words.device
+    mine = torch.tensor([int(words.numel()), int(tile_index.numel()), int(rec_bytes), int(n_matches)], dtype=torch.int64, device=device)
+    meta = torch.empty(world * 4, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(meta, mine)
+    meta = meta.view(world, 4).cpu().tolist()
+    if rank != dst:
+        if words.numel():
+            dist.send(words.contiguous(), dst=dst)
+        if tile_index.numel():
+            dist.send(tile_index.contiguous(), dst=dst)
+        return None
+    parts, reqs = [], []
+    for r in range(world):
+        nb, nt, rb, nm = (int(v) for v in meta[r])
+        if r == dst:
+            w, t = words, tile_index
+        else:
+            w = torch.empty(nb, dtype=torch.uint8, device=device)
+            t = torch.empty(nt, dtype=torch.int64, device=device)
+            if nb:
+                reqs.append(dist.irecv(w, src=r))
+            if nt:
+                reqs.append(dist.irecv(t, src=r))
+        parts.append({"words": w, "tix": t, "rec_bytes": rb, "n_matches": nm})
+    for q in reqs:
+        q.wait()
+    return parts
+
+
+def gather_packed(matcher, device: torch.device, slot: int = 0, d_records=None, dst: int = 0):
+    """``gather_packed_tensors`` for the slot's last finished scan: the heap words and the tile index are copied into
+    torch-owned device buffers (``pfac_records_packed_device``), the slot's stream is synchronised, then they travel."""
+    rb, n_tiles, used = matcher.scan_format(slot)
+    if rb == 8:
+        raise ValueError("automata beyond 2^20 final states write 8-byte records: use expanded_records + gather_records")
+    words = torch.empty(int(used) * rb, dtype=torch.uint8, device=device)
+    tix = torch.empty(int(n_tiles), dtype=torch.int64, device=device)
+    matcher.packed_to_device(words, tix, slot=slot, d_records=d_records)
+    matcher.sync(slot)
+    n_matches = int(matcher.last_count(slot))
+    return gather_packed_tensors(words, tix, rb, n_matches, dst=dst)
+
+
+def packed_to_records(words: np.ndarray, tile_index: np.ndarray, rec_bytes: int, base: int = 0) -> np.ndarray:
+    """Host-side expansion of one rank's compact part: structured array (pos u64, state u32), sorted by (position,
+    pattern length), positions = ``base`` + tile * 4096 + (word & 4095).  (numpy; for tests and small consumers --
+    ``emit_gathered`` prints without expanding.)"""
+    w = np.ascontiguousarray(words).view(np.uint16 if rec_bytes == 2 else np.uint32)
+    tix = np.ascontiguousarray(tile_index).view(np.uint64)
+    cnt = (tix >> np.uint64(40)).astype(np.int64)
+    first = (tix & np.uint64((1 << 40) - 1)).astype(np.int64)
+    n = int(cnt.sum())
+    out = np.empty(n, dtype=np.dtype([("pos", np.uint64), ("state", np.uint32)]))
+    if n == 0:
+        return out
+    tile_of = np.repeat(np.arange(tix.size, dtype=np.int64), cnt)
+    start = np.cumsum(cnt) - cnt
+    idx = first[tile_of] + (np.arange(n, dtype=np.int64) - start[tile_of])
+    ww = w[idx].astype(np.uint32)
+    out["pos"] = (np.uint64(base) + tile_of.astype(np.uint64) * np.uint64(4096) + (ww & np.uint32(4095)).astype(np.uint64))
+    out["state"] = ww >> np.uint32(12)
+    return out
+
+
+def emit_gathered(path, parts, idmap, n_total: int, threads: int = 1) -> int:
+    """``GPU_match_result.txt`` (main.cc:335-350) from a ``gather_packed`` result, rank by rank (== position order),
+    printed straight from the compact form by ``pfac_emit_packed`` with each rank's shard offset as base."""
+    import ctypes as C
+    import os
+    from ._ffi import PfacError, host_lib
+    L = host_lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    idm = np.ascontiguousarray(idmap, dtype=np.int32)
+    f = libc.fopen(os.fsencode(path), b"wb")
+    if not f:
+        raise PfacError(-2, f"cannot open {path}")
+    total = 0
+    try:
+        for r, p in enumerate(parts):
+            lo, _ = shard_range(n_total, r, len(parts))
+            w = np.ascontiguousarray(p["words"].cpu().numpy())
+            t = np.ascontiguousarray(p["tix"].cpu().numpy()).view(np.uint64)
+            n = L.pfac_emit_packed(f, w.ctypes.data, w.size // p["rec_bytes"], p["rec_bytes"], t.ctypes.data, t.size, int(lo),
+                                   idm.ctypes.data, int(threads))
+            if n < 0:
+                raise PfacError(int(n), "pfac_emit_packed")
+            total += int(n)
+    finally:
+        libc.fclose(f)
+    return total
 
 
 def split_gathered(gathered: torch.Tensor, counts: List[int], n_total: int, world: int) -> np.ndarray:

@@ -46,6 +46,7 @@ class GpuMatcher:
         self.n_streams = n_streams
         self.table: Optional[PfacTable] = None
         self._keep = {}
+        self._last_n = {}
         rc = self._L.pfac_ctx_create(int(device), int(n_streams), C.byref(self._ctx))
         if rc:
             self._ctx = C.c_void_p()
@@ -135,7 +136,15 @@ class GpuMatcher:
     def scan_finish(self, slot: int = 0, allow_overflow: bool = False) -> Tuple[int, bool]:
         n = C.c_uint64(0)
         rc = self._check(self._L.pfac_scan_finish(self._ctx, slot, C.byref(n)), allow_overflow=allow_overflow)
+        # the scan's end event is ordered after the slot's H2D copies on its stream: their host arrays can go
+        # (a streaming caller that never calls sync() would otherwise keep every chunk it ever uploaded alive)
+        self._keep.pop(slot, None)
+        self._last_n[slot] = n.value
         return n.value, rc == PFAC_E_OVERFLOW
+
+    def last_count(self, slot: int = 0) -> int:
+        """Match count of the slot's last finished scan."""
+        return self._last_n[slot]
 
     def elapsed_ms(self, slot: int = 0) -> float:
         ms = C.c_float(0)
@@ -175,6 +184,24 @@ class GpuMatcher:
         self._check(self._L.pfac_records_d2h_packed(self._ctx, slot, _ptr(d_records), words.ctypes.data, int(used), tix.ctypes.data))
         self.sync(slot)
         return words, tix[:nt]
+
+    def packed_to_host_into(self, host_words, host_tile_index, slot: int = 0, d_records=None) -> Tuple[int, int, int]:
+        """``packed_to_host`` into buffers the caller owns (e.g. pinned torch tensors: uint8[used * record_bytes],
+        int64[n_tiles]); synchronous.  Returns (record_bytes, n_tiles, used)."""
+        rb, nt, used = self.scan_format(slot)
+        self._check(self._L.pfac_records_d2h_packed(self._ctx, slot, _ptr(d_records), _ptr(host_words), int(used),
+                                                    _ptr(host_tile_index)))
+        self.sync(slot)
+        return rb, nt, used
+
+    def packed_to_device(self, d_words_out, d_tile_index_out, slot: int = 0, d_records=None) -> Tuple[int, int, int]:
+        """The compact form into DEVICE buffers the caller owns (torch tensors): heap words [0, used) -> ``d_words_out``
+        (None: leave them where the scan wrote them) and the tile index -> ``d_tile_index_out`` (int64[n_tiles]).
+        Asynchronous on the slot's stream.  Returns (record_bytes, n_tiles, used) -- what ``dist.gather_packed`` sends."""
+        rb, nt, used = self.scan_format(slot)
+        self._check(self._L.pfac_records_packed_device(self._ctx, slot, _ptr(d_records), _ptr(d_words_out), int(used),
+                                                       _ptr(d_tile_index_out)))
+        return rb, nt, used
 
     def checksum(self, n: int, base: int = 0, slot: int = 0, d_records=None) -> int:
         s = C.c_uint64(0)

@@ -221,7 +221,7 @@ def emit_packed(path, words: np.ndarray, tile_index: np.ndarray, idmap, base: in
     if not f:
         raise PfacError(-2, f"cannot open {path}")
     try:
-        n = L.pfac_emit_packed(f, words.ctypes.data, int(words.dtype.itemsize), tix.ctypes.data, tix.size, int(base),
+        n = L.pfac_emit_packed(f, words.ctypes.data, int(words.size), int(words.dtype.itemsize), tix.ctypes.data, tix.size, int(base),
                                None if idmap is None else idmap.ctypes.data, int(threads))
     finally:
         libc.fclose(f)

@@ -43,6 +43,8 @@ def lib():
         L.ac_num_states.argtypes = [vp]
         L.ac_scan_count.restype = C.c_int64; L.ac_scan_count.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_uint64)]
         L.ac_scan_collect.restype = C.c_int64; L.ac_scan_collect.argtypes = [vp, vp, C.c_int64, vp]
+        L.ac_scan_count_range.restype = C.c_int64
+        L.ac_scan_count_range.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)]
         _L = L
     return _L
 
@@ -137,3 +139,49 @@ def match_checksum(pos, ids):
         x ^= x >> np.uint64(29)
         x = x * np.uint64(0xBF58476D1CE4E5B9)
         return int(x.sum(dtype=np.uint64))
+
+
+def ac_whole_shard(pattern_file, buf, n_owned=None, base=0, threads=None, slice_bytes=32 << 20):
+    """(match count, checksum) of ONE serial Aho-Corasick pass over the whole buffer ``buf`` (numpy uint8, the bytes a
+    GPU scan read: n_avail = buf.size), counting the matches that START in [0, n_owned) -- computed on ``threads`` host
+    threads, each slice warmed up over the max_pat_len-1 bytes in front of it (oracle/ac_serial.c ac_scan_count_range).
+    The checksum is the one pfac_records_checksum computes on the GPU (sum of match_hash(base + pos, pattern id))."""
+    import threading
+    L = lib()
+    o = Oracle(pattern_file, 1, 1)
+    ac = L.ac_build(o.m)
+    maxlen = L.orc_max_len(o.m)
+    n_avail = int(buf.size)
+    n_owned = n_avail if n_owned is None else int(n_owned)
+    if threads is None:
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 1
+        threads = max(1, min(threads, 32))
+    cuts = list(range(0, n_avail, slice_bytes)) + [n_avail]
+    jobs = list(zip(cuts[:-1], cuts[1:]))          # hits ENDING in [a, b)
+    out = [(0, 0)] * len(jobs)
+    nxt = [0]
+    mu = threading.Lock()
+    addr = buf.ctypes.data
+
+    def work():
+        while True:
+            with mu:
+                k = nxt[0]
+                nxt[0] += 1
+            if k >= len(jobs):
+                return
+            a, b = jobs[k]
+            w = max(0, a - (maxlen - 1))           # cold start here
+            chk = C.c_uint64(0)
+            cnt = L.ac_scan_count_range(ac, addr + w, b - w, a - w, n_owned - w, base + w, C.byref(chk))   # (ctypes drops the GIL)
+            out[k] = (cnt, chk.value)
+
+    th = [threading.Thread(target=work) for _ in range(min(threads, max(1, len(jobs))))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    L.ac_free(ac)
+    o.close()
+    return sum(c for c, _ in out), sum(s for _, s in out) & (2**64 - 1)

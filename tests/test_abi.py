@@ -56,10 +56,12 @@ def test_product_never_touches_the_oracle():
 
 def test_reference_seam_library_exports_the_reference_names():
     """libpfac_seam.so defines the three functions main.cc:35-37 declares, with C++ linkage and the reference's
-    parameter lists (thread_data by value; the cudaStream_t is a void*)."""
+    parameter lists (thread_data by value; the cudaStream_t is accepted as a void* and as a hipStream_t)."""
     lib = os.path.join(_ffi.LIB_DIR, "libpfac_seam.so")
     blob = open(lib, "rb").read()
     for mangled in (b"_Z17GPU_Malloc_Memory11thread_dataPPhPPiS3_PPjS3_S3_", b"_Z14GPU_TraceTable11thread_dataPvPhPiS2_PjS2_S2_",
+                    # what main.cc:36 references once its cudaStream_t has become hipStream_t (= ihipStream_t *)
+                    b"_Z14GPU_TraceTable11thread_dataP12ihipStream_tPhPiS3_PjS3_S3_",
                     b"_Z15GPU_Free_memoryPPhPPiS2_PPjS2_S2_"):
         assert mangled in blob
     hdr = open(os.path.join(REPO, "include", "pfac_seam.h")).read()

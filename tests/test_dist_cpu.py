@@ -25,6 +25,29 @@ def _free_port():
     return p
 
 
+def pack_records(rec, n_owned, rec_bytes, seed):
+    """CPU stand-in for what the scan kernel leaves in HBM (include/pfac.h): a record HEAP of compact words
+    (pos & 4095 | state << 12), tiles placed in arbitrary order with gaps between them, plus the ordered tile index
+    (first | count << 40 per 4 KiB tile).  Returns (uint8 heap bytes, int64 tile index)."""
+    rng = np.random.default_rng(seed)
+    n_tiles = (n_owned + 4095) // 4096
+    tile = (rec["pos"] >> 12).astype(np.int64)
+    counts = np.bincount(tile, minlength=n_tiles).astype(np.int64)
+    first = np.zeros(n_tiles, dtype=np.int64)
+    at = 0
+    for t in rng.permutation(n_tiles):
+        at += int(rng.integers(0, 7))
+        first[t] = at
+        at += int(counts[t])
+    dt = np.uint16 if rec_bytes == 2 else np.uint32
+    words = rng.integers(0, 1 << (8 * rec_bytes), at + 3, dtype=np.uint64).astype(dt)       # garbage in the gaps
+    start = np.cumsum(counts) - counts
+    idx = first[tile] + (np.arange(rec.size) - start[tile])
+    words[idx] = ((rec["pos"] & 4095) | (rec["state"] << 12)).astype(dt)
+    tix = first.astype(np.uint64) | (counts.astype(np.uint64) << np.uint64(40))
+    return words.view(np.uint8).copy(), tix.view(np.int64).copy()
+
+
 def _worker(rank, world, port, pat_path, n_total, out_dir):
     sys.path.insert(0, REPO); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -64,6 +87,21 @@ def _worker(rank, world, port, pat_path, n_total, out_dir):
         np.save(os.path.join(out_dir, "counts.npy"), np.array(counts))
     else:
         assert gathered is None
+    # the COMPACT gather (what bench.py and a multi-GPU consumer use): heap words + tile index travel as they are
+    rec_bytes = 2 if table.num_final <= 16 else 4
+    wbytes, tix = pack_records(rec, hi - lo, rec_bytes, seed=100 + rank)
+    parts = pdist.gather_packed_tensors(torch.from_numpy(wbytes), torch.from_numpy(tix), rec_bytes, rec.size, dst=0)
+    if rank == 0:
+        assert [p["n_matches"] for p in parts] == counts and all(p["rec_bytes"] == rec_bytes for p in parts)
+        moved = sum(p["words"].numel() + 8 * p["tix"].numel() for p in parts)
+        assert moved < 8 * sum(counts) + 8 * sum(p["tix"].numel() for p in parts) + 64 * world       # fewer bytes than the 8-byte form
+        got = np.concatenate([pdist.packed_to_records(p["words"].numpy(), p["tix"].numpy(), p["rec_bytes"],
+                                                      base=pdist.shard_range(n_total, r, world)[0]) for r, p in enumerate(parts)])
+        np.save(os.path.join(out_dir, "packed.npy"), got)
+        nbytes = pdist.emit_gathered(os.path.join(out_dir, "packed.txt"), parts, table.idmap, n_total, threads=2)
+        assert nbytes == os.path.getsize(os.path.join(out_dir, "packed.txt"))
+    else:
+        assert parts is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,6 +124,13 @@ def test_two_rank_sharded_scan_reassembles(pattern, n_total, tmp_path):
     np.testing.assert_array_equal(got["pos"].astype(np.int64), pos)
     np.testing.assert_array_equal(table.idmap[got["state"]], ids)
     assert (np.diff(got["pos"].astype(np.int64)) >= 0).all()
+    # the compact gather reassembles the same sequence, and prints the reference's text from it
+    packed = np.load(tmp_path / "packed.npy")
+    np.testing.assert_array_equal(packed["pos"].astype(np.int64), pos)
+    np.testing.assert_array_equal(table.idmap[packed["state"]], ids)
+    exp = tmp_path / "expected.txt"
+    o.emit(whole, str(exp), spec=True)
+    assert (tmp_path / "packed.txt").read_bytes() == exp.read_bytes()
     o.close()
 
 

@@ -85,6 +85,50 @@ def test_gphf_cli_config1(resolve, tmp_path):
     assert (tmp_path / "GPU_match_result.txt").read_bytes() == exp.read_bytes()
 
 
+@pytest.mark.parametrize("workers,streams", [(2, 1), (3, 2), (4, 3)])
+def test_gphf_several_workers_share_the_emitter(workers, streams, resolve, tmp_path):
+    """The CLI's multi-GPU path (one host thread + context per worker, chunks dealt round-robin over the workers,
+    ONE in-order emitter, the bounded window between them -- gphf.c, replacing the OpenMP fan-out of main.cc:180-241)
+    with MORE THAN ONE worker: PFAC_WORKERS_PER_GPU runs them on this box's single device.  16 chunks of 1 MiB of the
+    reference's text under the 2 600-word dictionary (matches straddle every chunk boundary); the file must equal
+    the oracle's text byte for byte, whichever worker finished first."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "phfpfac_amd", "bin", "gphf")
+    para = open(resolve("paragraph402"), "rb").read()
+    n = 16 * (1 << 20) - 777
+    big = tmp_path / "big16.txt"
+    big.write_bytes(tiled_bytes(n + 1, para).tobytes())        # + the byte the CLI drops (main.cc:138)
+    env = dict(os.environ, PFAC_CHUNK_MB="1", PFAC_WORKERS_PER_GPU=str(workers), PFAC_READ_THREADS="2", PFAC_EMIT_THREADS="4")
+    out = subprocess.run([exe, resolve("xaa"), str(streams), "256", str(big)], cwd=tmp_path, env=env, capture_output=True,
+                         text=True, check=True).stdout
+    assert f"({workers} worker(s);" in out
+    assert sum(l.startswith("5.worker") for l in out.splitlines()) == workers
+    o = Oracle(resolve("xaa"), 1, 1)
+    exp = tmp_path / "expected.txt"
+    o.emit(tiled_bytes(n, para), str(exp), spec=True)
+    o.close()
+    assert (tmp_path / "GPU_match_result.txt").read_bytes() == exp.read_bytes()
+
+
+def test_bench_rank_code_at_the_c4_shard_size(tmp_path):
+    """Exactly what the driver's scaling run executes per rank: `bench.py --gpus 1` with the RCCL path forced
+    (table broadcast, count all-gather, compact record gather) at the C4 / C5 shard size of 4 GiB per GPU.  Its own
+    whole-shard parity check (count + checksum == serial Aho-Corasick over the 4 GiB copied back) must pass."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(HERE)
+    env = dict(os.environ, PFAC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--bytes-per-gpu", str(1 << 32), "--no-cpu-baseline", "--no-extra", "--no-end-to-end", "--sustain-seconds", "0.5"], env=env, cwd=tmp_path,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["bytes_per_gpu"] == 1 << 32
+    assert line["config"]["parity"].startswith("whole shard: count + checksum == serial AC")
+    assert line["config"]["matches_per_step"] > 300_000_000
+    assert "gather_ms" in line["config"] and line["value"] > 1000
+
+
 @pytest.mark.parametrize("width,env", [(256, {}), (1024, {}), (64, {}), (256, {"PFAC_NO_D1PACK": "1"}),
                                        (4096, {"PFAC_NO_NW4": "1"}), (256, {"PFAC_NO_FUSE": "1"}), (256, {"PFAC_NO_D1": "1"})])
 def test_dictionary_dense_mode_kernels(width, env, resolve, monkeypatch):
@@ -508,6 +552,16 @@ def test_errors_are_loud(resolve):
         n, over = g.scan_finish(0, allow_overflow=True)
         pos, _ = oracle_pairs(resolve("experimentpattern"), tiled_bytes(4096, open(resolve("paragraph402"), "rb").read()))
         assert over and n == pos.size > 16
+        # ... and records of an overflowed scan, or records past the match count, are refused, not delivered as garbage
+        with pytest.raises(PfacError):
+            g.records_to_host(8)
+        g.reserve(0, 0, 4096)
+        assert g.scan_resident(4096, 4096, d_input=buf) == n
+        assert g.records_to_host(n).size == n
+        with pytest.raises(PfacError):
+            g.records_to_host(n + 1)
+        with pytest.raises(PfacError):
+            g.records_to_host(2, first=n - 1)
 
 
 def test_rccl_path_single_rank(resolve):
@@ -540,16 +594,23 @@ def test_rccl_path_single_rank(resolve):
             assert rec_bytes == 4 and n_tiles == -(-(hi - lo) // 4096) and n <= used <= rec_t.numel()
             g.expand_records(n, wide_t, d_records=rec_t)                  # -> pfac_record, still on the device
             g.sync(0)
+            # the compact gather: heap words + tile index as the kernel wrote them (what bench.py --gpus N moves)
+            parts = pdist.gather_packed(g, dev, slot=0, d_records=rec_t, dst=0)
         counts = pdist.gather_counts(n, dev)
         assert counts == [n]
         gathered = pdist.gather_records(wide_t, n, counts, dst=0)
         got = pdist.split_gathered(gathered, counts, n_total, 1)
+        assert len(parts) == 1 and parts[0]["n_matches"] == n and parts[0]["rec_bytes"] == 4
+        assert parts[0]["words"].numel() < 8 * n
+        got2 = pdist.packed_to_records(parts[0]["words"].cpu().numpy(), parts[0]["tix"].cpu().numpy(), 4, base=lo)
     finally:
         dist.destroy_process_group()
     pos, ids = oracle_pairs(resolve("xaa"), data)
     assert got.size == pos.size
     np.testing.assert_array_equal(got["pos"].astype(np.int64), pos)
     np.testing.assert_array_equal(table.idmap[got["state"]], ids)
+    np.testing.assert_array_equal(got2["pos"].astype(np.int64), pos)
+    np.testing.assert_array_equal(table.idmap[got2["state"]], ids)
 
 
 def test_deeply_nested_patterns_every_offset_matches_hundreds(tmp_path):

@@ -284,3 +284,10 @@ def test_emit_from_record_heap_and_tile_index(tmp_path):
     # no tiles at all / only empty tiles
     assert emit_packed(str(b), np.zeros(1, np.uint32), np.zeros(0, np.uint64), idmap) == 0
     assert emit_packed(str(b), np.zeros(1, np.uint32), np.zeros(9, np.uint64), idmap) == 0
+    # a tile index that points past the heap copy it is paired with (an index copied after an overflowed scan, a short
+    # copy): refused, nothing read out of bounds
+    need = int((first + counts.astype(np.uint64))[counts > 0].max())
+    assert emit_packed(str(b), words[:need], tix, idmap) == emit_records(str(a), rec, idmap)
+    for short in (words[: need - 1], words[:1]):
+        with pytest.raises(PfacError):
+            emit_packed(str(b), short, tix, idmap)
