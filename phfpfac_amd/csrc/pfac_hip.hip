@@ -105,6 +105,9 @@ constexpr bool MASK_GATHERS = PFAC_MASK_GATHERS != 0;   // fused walks: exec-mas
 #define PFAC_LOAD_AUX 2
 #endif
 constexpr int LOAD_AUX = PFAC_LOAD_AUX;    // cache policy of the tile loads (0 default, 2 = nt: the input is read once)
+#ifndef PFAC_PAIR_DENSITY_PCT
+#define PFAC_PAIR_DENSITY_PCT 40              // level-2 filter: flags only (mode 3) from this share of (first, second) byte combinations on
+#endif
 constexpr int QDEEP = 0x8000;              // FIFO entry = tile-local position | QDEEP when the survivor needs a walk
 // per-wave LDS: tile bytes + halo | survivor FIFO | nbuf record staging buffers.  A tile's records leave nbuf - 1 rounds
 // after it was scanned (its record base needs every count of its round).  nbuf = 3 where LDS allows: the stores then
@@ -162,13 +165,14 @@ struct ScanArgs {
     int d1_rows;                          // 0: no dense level
     int d1_stride, d1_ncols, d1_lds_bytes;  // LDS row length in words (columns, + 1 "no edge" unless all 256 are used);
                                           // columns; bytes of the LDS rows (multiple of 16)
-    const int *d1r2;                      // FUSED + packed dense rows: r[] of the depth-2 states, d1_n2 words (else null)
+    const int2 *d1r2;                     // FUSED + packed dense rows: {r[], child mask} of the depth-2 states, d1_n2 entries (else null)
     int d1_n2;                            // > 0: a dense-row entry is  state | index into d1r2 << 20  (or -1)
     unsigned root_byte;                   // ROOT == 1: the only byte with a root edge, replicated x4
     int root_state;                       // ROOT == 1: the state that byte leads to (every survivor starts there)
     // level-2 filter (which survivors can go beyond their second byte):
     //   0 off: every survivor is walked        1 (ROOT == 1): SWAR compare with <= 2 child bytes of root_state
     //   2: one lookup per survivor in the 2-byte-prefix bitmap (bm2_rows = 256 rows of 32 bytes; ROOT == 1: its one row)
+    //   3 (ROOT == 0, sec_filter): second-byte flags only -- survivors whose next byte can be a second byte are all walked
     int l2f_mode;
     unsigned child0, child1;              // mode 1: the child bytes, replicated x4 (n_child 1: child1 == child0)
     int n_child;                          // mode 1: 0 (nothing is ever deep), 1 or 2
@@ -348,14 +352,17 @@ __device__ __forceinline__ int phf_step(const int *R, const int2 *T, int state, 
 //    and stops there.
 template <bool W8, int NWALK, bool FUSED, int MREG, int ROOT>
 __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, int root_state, const unsigned char *d1idx,
-                                      const unsigned char *colmap, unsigned d1_stride, const int *D1, bool dense1, const int *D1R2, const int *S0R, const int *R, const int2 *T, const int4 *T4,
+                                      const unsigned char *colmap, unsigned d1_stride, const int *D1, bool dense1, const int2 *D1R2, const int *S0R, const int *R, const int2 *T, const int4 *T4,
                                       const unsigned (&pos)[NWALK], const bool (&active)[NWALK], const bool (&deepf)[NWALK],
                                       unsigned lim, int wbit,
-                                      int ht_size, int num_final, int rn_bias, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
+                                      int ht_size, int num_final, int rn_bias, bool skip_s0, unsigned (&n)[NWALK], unsigned (&m)[NWALK][MREG]) {
     static_assert(MREG == 2 || MREG == 4, "two or four final states per walk in registers");
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
     unsigned win[NWALK], left[NWALK], f[NWALK];                // left: bytes the walk may still read after its first
     int s[NWALK], rn[NWALK];                                   // rn: r[row of s] (FUSED)
+    unsigned cm[NWALK];                                        // FUSED: child mask of s -- bit (b & 31) set iff s has an edge on some byte
+                                                               // congruent to b mod 32 (all ones where it is not known): a walker whose next
+                                                               // byte's bit is clear is dead WITHOUT the L2 round trip that would say so
     bool go[NWALK];
     unsigned k = 0;                                            // transitions made so far (the same for every walk: a scalar)
     const int sub = wbit - 8;                                  // FUSED needs wbit >= 8: row = state >> sub
@@ -367,7 +374,8 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     }
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
-        const int st = ROOT == 1 ? root_state : s0[win[w] & 0xFFu];
+        // (dense second byte and no 1-byte pattern: the depth-1 state itself is never looked at -- any live, non-final value will do)
+        const int st = ROOT == 1 ? root_state : (skip_s0 ? num_final : s0[win[w] & 0xFFu]);
         f[w] = ROOT == 1 ? 0u : d1idx[win[w] & 0xFFu];        // dense row of that state (when dense1)
         s[w] = active[w] ? st : -1;
         n[w] = 0;
@@ -376,10 +384,13 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         left[w] = (deepf[w] && lim > pos[w] + 1u) ? lim - pos[w] - 1u : 0u;
         go[w] = false;
         rn[w] = 0;
+        cm[w] = 0xFFFFFFFFu;
     }
     // account for the states just reached; false when no lane of the wave can go on.
     // final <=> (unsigned)s < num_final, which also rejects the dead state -1.
-    auto reached = [&]() -> bool {
+    // masked (FUSED): byte `bi` of the window is the NEXT byte of the walk; a walker whose state has no edge on any byte
+    // congruent to it mod 32 (child mask) is dead here and now -- no gather, and the loop can end a step earlier
+    auto reached = [&](int bi, bool masked) -> bool {
         bool any = false;
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
@@ -391,6 +402,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             m[w][0] = fin ? (unsigned)s[w] : m[w][0];
             n[w] += fin ? 1u : 0u;
             go[w] = s[w] >= 0 && k < left[w];
+            if (FUSED && masked) go[w] = go[w] && ((cm[w] >> ((win[w] >> (8 * bi)) & 31u)) & 1u) != 0u;
             any = any || go[w];
         }
         return __any(any);
@@ -439,6 +451,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             for (int w = 0; w < NWALK; w++) {
                 s[w] = (go[w] && e4[w].x == row[w]) ? e4[w].y : -1;
                 rn[w] = e4[w].z;
+                cm[w] = (unsigned)e4[w].w;
             }
             k++;
             return;
@@ -476,7 +489,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             for (int w = 0; w < NWALK; w++) rn[w] = R[(go[w] ? s[w] : 0) >> sub] + rn_bias;
         }
     };
-    if (!reached()) return;
+    if (!reached(1, false)) return;
     if (dense1) {
         // second byte: the depth-1 state's row is dense in LDS -- one lookup, no hash, no owner check
 #pragma unroll
@@ -487,7 +500,9 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
                 // needs no r[] gather either
                 const bool ok = go[w] && nx >= 0;
                 s[w] = ok ? (nx & ((1 << D1_STATE_BITS) - 1)) : -1;
-                rn[w] = D1R2[ok ? (nx >> D1_STATE_BITS) : 0];
+                const int2 e2 = D1R2[ok ? (nx >> D1_STATE_BITS) : 0];      // {r[] of the depth-2 state, its child mask}
+                rn[w] = e2.x;
+                cm[w] = (unsigned)e2.y;
             } else {
                 s[w] = go[w] ? nx : -1;
             }
@@ -504,25 +519,34 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
         }
         step(1);
     }
-    if (!reached()) return;
+    if (!reached(2, true)) return;
     if (dense1 && !(FUSED && D1R2)) load_rn();
     step(2);
-    if (!reached()) return;
+    if (!reached(3, true)) return;
     step(3);
     for (;;) {                                                 // deeper than 4 bytes: next aligned windows
-        if (!reached()) return;
+        if (!reached(0, false)) return;
 #pragma unroll
         for (int w = 0; w < NWALK; w++) {
             const unsigned p = pos[w] + 1u + k;                // next byte of the walk
             const unsigned lo = t32[p >> 2], hi = t32[(p >> 2) + 1];
             win[w] = __builtin_amdgcn_alignbyte(hi, lo, p & 3u);
         }
+        if (FUSED) {                                           // the child masks against the first byte of the new windows
+            bool any = false;
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) {
+                go[w] = go[w] && ((cm[w] >> (win[w] & 31u)) & 1u) != 0u;
+                any = any || go[w];
+            }
+            if (!__any(any)) return;
+        }
         step(0);
-        if (!reached()) return;
+        if (!reached(1, true)) return;
         step(1);
-        if (!reached()) return;
+        if (!reached(2, true)) return;
         step(2);
-        if (!reached()) return;
+        if (!reached(3, true)) return;
         step(3);
     }
 }
@@ -567,7 +591,7 @@ struct Dense1 {
     const unsigned char *idx;
     const int *rows;
     bool on;
-    const int *r2;      // packed rows (FUSED): r[] of the depth-2 states, in LDS; null = plain rows
+    const int2 *r2;     // packed rows (FUSED): {r[], child mask} of the depth-2 states, in LDS; null = plain rows
     const int *s0r;     // no dense rows (FUSED): r[] of the depth-1 state each root byte leads to, in LDS; else null
 };
 
@@ -608,7 +632,7 @@ __device__ __forceinline__ unsigned roundN(const ScanArgs &a, const unsigned cha
         return nact;
     }
     walkN<W8, NWALK, FUSED, MREG, ROOT>(tile, s0, a.root_state, d1.idx, d1.colmap, (unsigned)a.d1_stride, d1.rows, d1.on, d1.r2, d1.s0r, R, T, a.T4, pos, active, deepf, lim,
-                                        a.wbit, a.ht_size, a.num_final, a.rn_bias, n, m);
+                                        a.wbit, a.ht_size, a.num_final, a.rn_bias, ROOT != 1 && d1.on && a.sec_filter != 0, n, m);
     // the walk kept its latest MREG final states as a shift register (m[0] = latest): back into walk order
 #pragma unroll
     for (int w = 0; w < NWALK; w++) {
@@ -676,7 +700,7 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
                                                         const unsigned (&deep)[MSUBS], int lane,
                                                         unsigned lim, unsigned long long tile_base,
                                                         unsigned long long wrun) {
-    unsigned tail = 0;                         // pending survivors, always < one round between appends
+    unsigned head = 0, tail = 0;               // pending survivors: q[head, tail), always fewer than one round between appends
     // per-lane survivor counts of the 2 half-tiles, prefix-summed in one packed DPP scan (16-bit fields: a
     // half-tile holds at most 2048 survivors)
     static_assert(MSUBS == 2, "the packed scan assumes 2 half-tiles");
@@ -746,6 +770,17 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
                 gcnt = __builtin_amdgcn_readlane(incl, 16 * gi + 15) - gbase;
                 mine = (lane >> 4) == gi;
             }
+            if (tail + gcnt > (unsigned)QCAP) {    // no room behind the pending entries (fewer than one round of them): move them to the front
+                const unsigned rem = tail - head;
+                unsigned short v[NWALK];
+#pragma unroll
+                for (int w = 0; w < NWALK; w++) v[w] = (unsigned)lane + WAVE * w < rem ? q[head + WAVE * w + lane] : (unsigned short)0;
+                wave_lds_sync();
+#pragma unroll
+                for (int w = 0; w < NWALK; w++) if ((unsigned)lane + WAVE * w < rem) q[WAVE * w + lane] = v[w];
+                head = 0;
+                tail = rem;
+            }
             if (mine) {
                 unsigned o = tail + (incl - cnt) - gbase;
                 for (unsigned m = mask; m; m &= m - 1) {
@@ -755,28 +790,17 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
             }
             tail += gcnt;
             wave_lds_sync();
-            unsigned h = 0;
-            for (; h + RW <= tail; h += RW)
-                TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, h, RW, lane, stage, lim, tile_base, wrun)));
-            if (h) {                               // move the < RW left-overs to the front
-                const unsigned rem = tail - h;
-                unsigned short v[NWALK];
-#pragma unroll
-                for (int w = 0; w < NWALK; w++) v[w] = (unsigned)lane + WAVE * w < rem ? q[h + WAVE * w + lane] : (unsigned short)0;
-                wave_lds_sync();
-#pragma unroll
-                for (int w = 0; w < NWALK; w++) if ((unsigned)lane + WAVE * w < rem) q[WAVE * w + lane] = v[w];
-                wave_lds_sync();
-                tail = rem;
-            }
+            for (; head + RW <= tail; head += RW)
+                TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, head, RW, lane, stage, lim, tile_base, wrun)));
         }
     }
-    if (tail) TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, 0, tail, lane, stage, lim, tile_base, wrun)));
+    // (the last, partial round runs where its entries lie: nothing is appended behind them any more)
+    if (tail > head) TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, head, tail - head, lane, stage, lim, tile_base, wrun)));
 #ifdef PFAC_TRACE_BUILD
     if (!DIRECT && a.dbg && blockIdx.x < 8 && lane == 0 && (threadIdx.x >> 6) == 0) {
         // compute wave 0 of the first 8 workgroups: accumulated over the launch (slot 31 of the block's first row)
         unsigned long long *acc = a.dbg + (size_t)blockIdx.x * 64 * 32 + 10;      // columns 10..14 of the block's row 0
-        acc[0] += tp_round; acc[1] += tp_n; acc[2] += __builtin_amdgcn_s_memrealtime() - tp_t0; acc[3] += 1; acc[4] += tail;
+        acc[0] += tp_round; acc[1] += tp_n; acc[2] += __builtin_amdgcn_s_memrealtime() - tp_t0; acc[3] += 1; acc[4] += tail - head;
     }
 #endif
     return wrun;
@@ -791,6 +815,15 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
 #ifdef PFAC_ABL_NOEMIT                         // ablation builds only: records never leave LDS
     return;
 #endif
+    if (cnt <= 2u * WAVE && a.rec_bytes == 4 && base + cnt <= a.out_cap) {
+        // a sparse tile (the L2-table workloads: tens of records): one record per lane per store, two independent trips
+        // -- the aligned 16-byte form below pays three dependent LDS round trips (head, body, tail) for a few hundred bytes
+        unsigned *out = static_cast<unsigned *>(a.out);
+        const unsigned v0 = (unsigned)lane < cnt ? stage[lane] : 0u, v1 = (unsigned)lane + WAVE < cnt ? stage[lane + WAVE] : 0u;
+        if ((unsigned)lane < cnt) __builtin_nontemporal_store(v0, out + base + lane);
+        if ((unsigned)lane + WAVE < cnt) __builtin_nontemporal_store(v1, out + base + lane + WAVE);
+        return;
+    }
     if (a.rec_bytes == 2) {
         // automata with at most 16 final states: the record is the low half of the staged word; eight per 16-byte store
         unsigned short *out = static_cast<unsigned short *>(a.out);
@@ -886,6 +919,9 @@ __device__ __forceinline__ unsigned eq_mask32(const u32x4 lo16, const u32x4 hi16
 // The scan kernel.  Workgroups share the read-only tables staged in LDS once; after that there is
 // no workgroup barrier: compute waves pipeline  [loads of round r+1 in flight | scan round r |
 // emit round r-2]  and meet the coordinator only through the LDS rings above.
+#ifndef PFAC_SPARSE_FUSED_NW
+#define PFAC_SPARSE_FUSED_NW 2
+#endif
 constexpr int MAX_WAVES_NW4 = 10;          // four walks per lane need registers: at most 10 waves per workgroup (dense mode has 9-10)
 
 template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB>
@@ -927,9 +963,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     } else {
         for (int i = tid; i < 256; i += blockDim.x) { d1idx_l[i] = 0; colmap_l[i] = 0; }
     }
-    int *d1r2_l = reinterpret_cast<int *>(smem + SH_D1 + a.d1_lds_bytes);
+    int2 *d1r2_l = reinterpret_cast<int2 *>(smem + SH_D1 + a.d1_lds_bytes);
     if (FUSED && a.d1_n2 > 0)
-        for (int i = tid; i < a.d1_n2; i += blockDim.x) d1r2_l[i] = a.d1r2[i] + a.rn_bias;
+        for (int i = tid; i < a.d1_n2; i += blockDim.x) { const int2 e = a.d1r2[i]; d1r2_l[i] = make_int2(e.x + a.rn_bias, e.y); }
     // FUSED without dense rows: r[] of the depth-1 states by root byte, in the (unused) dense-row region
     int *s0r_l = reinterpret_cast<int *>(smem + SH_D1);
     const bool have_s0r = FUSED && a.d1_rows == 0;
@@ -1173,6 +1209,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         unsigned long long t_far = 0;
         const bool more_far = (LOAD_DEPTH == 1 || have_n1) && probe(r + LOAD_DEPTH, t_far);
         if (more_far) issue_loads(t_far, w, hw);
+        PFAC_STAMP(trace && r > 0, 10);
         // ---- emit the tile of `lag` rounds ago: its bases came when that round's last count was in (a tile without
         // records has nothing to wait for: the coordinator stores the tile index).  Its buffer is the one after the
         // current round's, cyclically.
@@ -1185,6 +1222,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             }
         };
         if (NB == 3) emit_pending(pend_have[LAG_MAX - 1], pend_cnt[LAG_MAX - 1]);      // stores right behind the loads
+        PFAC_STAMP(trace && r > 0, 11);
 
         // ---- root test -> 32-bit survivor mask per lane per half-tile; level-2 filter -> which of them are kept
         // (yield a record or need a walk) and which of those are deep (need the walk)
@@ -1200,6 +1238,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             const unsigned rlo = root_mask<ROOT>(lo16, ftab, a.root_byte), rhi = root_mask<ROOT>(hi16, ftab, a.root_byte);
 #endif
             const unsigned raw = (rlo & 0xFFFFu) | (rhi << 16);
+#ifdef PFAC_TRACE_BUILD
+            asm volatile("" :: "v"(raw));
+            PFAC_STAMP(trace && r > 0, j == 0 ? 12 : 14);
+#endif
             unsigned m1 = raw;
             if (tile_base + WTILE > a.n_owned) {   // last tile only: offsets at or past n_owned start no walk
                 const unsigned long long g = tile_base + off;
@@ -1241,6 +1283,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #ifdef PFAC_ABL_NOCLASS                        // ablation builds only: no survivor is looked up (no records)
                 cand = 0;
 #endif
+                if (ROOT != 1 && a.l2f_mode == 3) {
+                    // dense pair matrix (most flagged first bytes are followed by most flagged second bytes in the
+                    // trie): the per-survivor bitmap lookup -- a serial, per-lane chain of LDS round trips -- would drop
+                    // few of these, so they all go to the walk, whose dense depth-1 row IS the pair lookup, 64 lanes wide
+                    dm = cand;
+                    cand = 0;
+                }
                 for (unsigned mm = cand; mm;) {
                     unsigned b[L2F_UNROLL], win[L2F_UNROLL], v[L2F_UNROLL], fin[L2F_UNROLL];
                     bool on[L2F_UNROLL];
@@ -1269,6 +1318,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                 deep[j] = dm;
                 keep[j] = dm | (ROOT == 1 ? (root_final ? m1 : 0u) : fm);
             }
+#ifdef PFAC_TRACE_BUILD
+            asm volatile("" :: "v"(keep[j]), "v"(deep[j]));
+            PFAC_STAMP(trace && r > 0 && j == 0, 13);
+#endif
         }
 
 #ifdef PFAC_ABL_NOKEEP                         // ablation builds only: survivors classified, then dropped (no records)
@@ -1358,7 +1411,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 
 template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB = 2>
 __global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLOCK)) void pfac_scan_kernel(ScanArgs a) {
-    static_assert(NB == 2 || (NB == 3 && NW <= 2), "three staging buffers: the sparse-mode kernels (dense mode has one)");
+    static_assert(NB == 2 || (NB == 3 && NW <= 3), "three staging buffers: the sparse-mode kernels (dense mode has one)");
     static_assert(!(TLDS && FUSED), "the fused table is for tables gathered through L2");
     static_assert(NW == (TLDS ? 1 : 2) || (FUSED && (NW == 3 || NW == 4)), "walks per lane: 1 (LDS tables), 2 (L2 tables), 3 (L2, fused), 4 (L2, fused, dense matches)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1419,6 +1472,23 @@ __global__ void pfac_repack_kernel(const int *blob, int *s0, int *r, int2 *T, in
     if (!ok) *bad = 1;
 }
 
+// Child mask of a state (the fused walk's prefilter): bit (c & 31) set iff the state has an edge on byte c.
+__device__ __forceinline__ unsigned child_mask32(const int *r, const int2 *T, int wbit, int ht_size, int max_row, int state) {
+    unsigned m = 0;
+    if (state < 0) return 0u;
+    for (int c = 0; c < 256; c++) {
+        const int key = (state << 8) | c;
+        const int row = key >> wbit;
+        if (row >= max_row) continue;
+        const int idx = r[row] + (key & ((1 << wbit) - 1));
+        if ((unsigned)idx < (unsigned)ht_size) {
+            const int2 e = T[idx];
+            if (e.x == row && e.y >= 0) m |= 1u << (c & 31);
+        }
+    }
+    return m;
+}
+
 // Fused slots for tables gathered through L2 (PHF width >= 256): T4[i] = {owner row, next state, r[row of next], 0}.
 // (slots [lo, hi) with lo <= min(r), hi >= max(r) + width: the table image holds [0, ht_size) -- displacements may be
 // negative and the image ends at its last used slot -- but the fused walk indexes unchecked; the slots outside the
@@ -1433,7 +1503,9 @@ __global__ void pfac_fuse_kernel(const int2 *T, const int *r, int wbit, int ht_s
             const int row = e.y >> (wbit - 8);
             if (row < max_row) { rn = r[row]; have = true; }
         }
-        T4[i] = make_int4(e.x, e.y, have ? rn - lo : 0, 0);
+        // .w: the child mask of the next state -- what lets the walk drop a walker without the gather that would
+        // (only owned slots are ever selected, so an unowned slot's mask is never used)
+        T4[i] = make_int4(e.x, e.y, have ? rn - lo : 0, e.x >= 0 ? (int)child_mask32(r, T, wbit, ht_size, max_row, e.y) : 0);
     }
 }
 
@@ -1452,15 +1524,16 @@ __global__ void pfac_build_d1_kernel(const int *d1state, const int *r, const int
     d1[blockIdx.x * 256 + c] = nx;
 }
 
-// FUSED: pack the dense rows in place -- entry = state | k << 20 with r2[k] = r[row of that state]; *counter hands out k.
-__global__ void pfac_pack_d1_kernel(int *d1, int n_entries, const int *r, int wbit, int max_row, int *r2, int *counter) {
+// FUSED: pack the dense rows in place -- entry = state | k << 20 with r2[k] = {r[row of that state], its child mask};
+// *counter hands out k.
+__global__ void pfac_pack_d1_kernel(int *d1, int n_entries, const int *r, const int2 *T, int wbit, int ht_size, int max_row, int2 *r2, int *counter) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     const int nx = d1[i];
     if (nx < 0) return;
     const int k = atomicAdd(counter, 1);
     const int row = nx >> (wbit - 8);
-    r2[k] = row < max_row ? r[row] : -1;
+    r2[k] = make_int2(row < max_row ? r[row] : -1, (int)child_mask32(r, T, wbit, ht_size, max_row, nx));
     d1[i] = nx | (k << D1_STATE_BITS);
 }
 
@@ -1781,6 +1854,11 @@ static int max_lds(const pfac_ctx *ctx) {
     return v;
 }
 
+// layout of pfac_ctx::d_d1: rows (d1_rows x 256 int32) | 256-byte row index | the depth-1 states | (packed rows) {r[], child
+// mask} of the depth-2 states (8-byte aligned) | counter | column map | column bytes
+size_t d1_off_r2(int d1_rows) { return align_up((size_t)d1_rows * 1024 + 256 + (size_t)d1_rows * 4, 8); }
+size_t d1_off_col(int d1_rows) { return d1_off_r2(d1_rows) + (size_t)D1_N2_MAX * 8 + 16; }
+
 int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     // table bytes if staged in LDS: r (16-B rounded) + T
     const size_t tbytes = align_up((size_t)ctx->max_row * 4, 16) + (size_t)ctx->ht_size * 8;
@@ -1804,10 +1882,8 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->d1_n2 = 0;
     if (ctx->d_d1) { HIP_TRY(ctx, hipFree(ctx->d_d1)); ctx->d_d1 = nullptr; }
     if (ctx->d1_rows) {
-        // layout: rows | 256-byte row index | the depth-1 states | (packed rows) r[] of the depth-2 states | counter |
-        // column map | column bytes
-        const size_t off_r2 = (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4;
-        const size_t off_col = off_r2 + (size_t)D1_N2_MAX * 4 + 16;
+        const size_t off_r2 = d1_off_r2(ctx->d1_rows);
+        const size_t off_col = d1_off_col(ctx->d1_rows);
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_d1, off_col + 512));
         unsigned char *b = reinterpret_cast<unsigned char *>(ctx->d_d1);
         int *d_state = reinterpret_cast<int *>(b + (size_t)ctx->d1_rows * 1024 + 256);
@@ -1847,18 +1923,18 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
             int n2 = 0;
             for (int v : rows) n2 += v >= 0;
             if (n2 >= 1 && n2 <= D1_N2_MAX) {
-                int *r2 = reinterpret_cast<int *>(b + off_r2);
-                int *counter = r2 + D1_N2_MAX;
+                int2 *r2 = reinterpret_cast<int2 *>(b + off_r2);
+                int *counter = reinterpret_cast<int *>(r2 + D1_N2_MAX);
                 HIP_TRY(ctx, hipMemset(counter, 0, 4));
                 hipLaunchKernelGGL(pfac_pack_d1_kernel, dim3((unsigned)ctx->d1_rows), dim3(256), 0, 0, ctx->d_d1,
-                                   ctx->d1_rows * 256, ctx->d_r, ctx->width_bit, ctx->max_row, r2, counter);
+                                   ctx->d1_rows * 256, ctx->d_r, ctx->d_T, ctx->width_bit, ctx->ht_size, ctx->max_row, r2, counter);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipDeviceSynchronize());
                 ctx->d1_n2 = n2;
             }
         }
     }
-    ctx->shared_bytes = SH_D1 + ctx->d1_lds_bytes + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 4, 16));
+    ctx->shared_bytes = SH_D1 + ctx->d1_lds_bytes + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 8, 16));
     if (fused && ctx->d1_rows == 0) ctx->shared_bytes += 1024;   // r[] of the depth-1 states by root byte
     // ---- level-2 filter: the 2-byte-prefix bitmap is built on the device from the uploaded tables; a single-edge
     // root with at most two grandchildren gets the bit-parallel form (their bytes), everything else the lookup form
@@ -1895,9 +1971,19 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
             ctx->child1 = (unsigned)ch[nch > 1 ? 1 : 0] * 0x01010101u;
         }
     }
-    const int l2f_env = env_int("PFAC_L2F", -1);          // 0: filter off; 2: lookup form even where the SWAR form applies
+    // multi-edge root without 1-byte patterns: when most (first byte, second byte) combinations of the flagged bytes
+    // ARE 2-byte prefixes, the bitmap lookup would drop few of the survivors the second-byte flags let through -- they
+    // all go to the walk instead (mode 3), whose dense depth-1 row is the same lookup done 64 lanes wide
+    if (fan != 1 && ctx->sec_filter) {
+        long pairs = 0, nsec = 0;
+        for (int i = 0; i < 256 * 32; i++) pairs += __builtin_popcount(bm2_host[(size_t)i]);
+        for (int c = 0; c < 256; c++) nsec += bm2_host[256 * 32 + c];
+        if (nsec > 0 && pairs * 100 >= (long)fan * nsec * PFAC_PAIR_DENSITY_PCT) ctx->l2f_mode = 3;
+    }
+    const int l2f_env = env_int("PFAC_L2F", -1);          // 0: filter off; 2: lookup form even where the SWAR / flag-only form applies; 3: flags only
     if (l2f_env == 0) ctx->l2f_mode = 0;
     else if (l2f_env == 2) ctx->l2f_mode = 2;
+    else if (l2f_env == 3 && fan != 1 && ctx->sec_filter) ctx->l2f_mode = 3;
     ctx->sh_bm2 = ctx->shared_bytes;
     if (ctx->l2f_mode == 2) ctx->shared_bytes += ctx->bm2_rows * 32;
     // knobs (tuning and tests), read once per table install
@@ -1981,13 +2067,14 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipDeviceSynchronize());
     }
+    constexpr int FNW = PFAC_SPARSE_FUSED_NW;   // walks per lane of the sparse-mode kernels on fused L2 tables
     const void *k[4][2][2] = {
         {{(const void *)pfac_scan_kernel<false, false, 0, false, 2>, (const void *)pfac_scan_kernel<false, false, 1, false, 2>},
          {(const void *)pfac_scan_kernel<false, true, 0, false, 2>, (const void *)pfac_scan_kernel<false, true, 1, false, 2>}},
         {{(const void *)pfac_scan_kernel<true, false, 0, false, 1>, (const void *)pfac_scan_kernel<true, false, 1, false, 1>},
          {(const void *)pfac_scan_kernel<true, true, 0, false, 1>, (const void *)pfac_scan_kernel<true, true, 1, false, 1>}},
-        {{(const void *)pfac_scan_kernel<false, false, 0, true, 2>, (const void *)pfac_scan_kernel<false, false, 1, true, 2>},
-         {(const void *)pfac_scan_kernel<false, true, 0, true, 2>, (const void *)pfac_scan_kernel<false, true, 1, true, 2>}},
+        {{(const void *)pfac_scan_kernel<false, false, 0, true, FNW>, (const void *)pfac_scan_kernel<false, false, 1, true, FNW>},
+         {(const void *)pfac_scan_kernel<false, true, 0, true, FNW>, (const void *)pfac_scan_kernel<false, true, 1, true, FNW>}},
         {{(const void *)pfac_scan_kernel<false, false, 0, true, 4>, (const void *)pfac_scan_kernel<false, false, 1, true, 4>},
          {(const void *)pfac_scan_kernel<false, true, 0, true, 4>, (const void *)pfac_scan_kernel<false, true, 1, true, 4>}}};
     // (three walks per lane for the sparse fused kernels -- one round per tile of the 75 840-pattern set on random bytes
@@ -2001,8 +2088,8 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
              {(const void *)pfac_scan_kernel<false, true, 0, false, 2, 3>, (const void *)pfac_scan_kernel<false, true, 1, false, 2, 3>}},
             {{(const void *)pfac_scan_kernel<true, false, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, false, 1, false, 1, 3>},
              {(const void *)pfac_scan_kernel<true, true, 0, false, 1, 3>, (const void *)pfac_scan_kernel<true, true, 1, false, 1, 3>}},
-            {{(const void *)pfac_scan_kernel<false, false, 0, true, 2, 3>, (const void *)pfac_scan_kernel<false, false, 1, true, 2, 3>},
-             {(const void *)pfac_scan_kernel<false, true, 0, true, 2, 3>, (const void *)pfac_scan_kernel<false, true, 1, true, 2, 3>}}};
+            {{(const void *)pfac_scan_kernel<false, false, 0, true, FNW, 3>, (const void *)pfac_scan_kernel<false, false, 1, true, FNW, 3>},
+             {(const void *)pfac_scan_kernel<false, true, 0, true, FNW, 3>, (const void *)pfac_scan_kernel<false, true, 1, true, FNW, 3>}}};
         ctx->kernel3 = k3[ctx->variant == 0 ? 1 : (fused ? 2 : 0)][w8 ? 1 : 0][ctx->root_mode];
         HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
     }
@@ -2260,13 +2347,10 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.halo = ctx->halo;
         a.shared_bytes = ctx->shared_bytes; a.pw_bytes = dense ? ctx->pw_bytes_d : L.pw_bytes;
         a.d1 = ctx->d_d1; a.d1_rows = ctx->d1_rows; a.d1_stride = ctx->d1_stride; a.d1_ncols = ctx->d1_ncols; a.d1_lds_bytes = ctx->d1_lds_bytes;
-        a.d1_colmap = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 + 256 +
-                                      (size_t)ctx->d1_rows * 4 + (size_t)D1_N2_MAX * 4 + 16
-                                : nullptr;
+        a.d1_colmap = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + d1_off_col(ctx->d1_rows) : nullptr;
         a.d1_colbyte = a.d1_colmap ? a.d1_colmap + 256 : nullptr;
         a.d1_n2 = ctx->d1_n2;
-        a.d1r2 = ctx->d1_n2 ? reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ctx->d_d1) +
-                                                            (size_t)ctx->d1_rows * 1024 + 256 + (size_t)ctx->d1_rows * 4)
+        a.d1r2 = ctx->d1_n2 ? reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(ctx->d_d1) + d1_off_r2(ctx->d1_rows))
                             : nullptr;
         a.d1idx = ctx->d_d1 ? reinterpret_cast<const unsigned char *>(ctx->d_d1) + (size_t)ctx->d1_rows * 1024 : nullptr;
         a.root_byte = ctx->root_byte;

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "trace.bin")
 os.environ["PFAC_TRACE"] = out
-os.environ["PFAC_HIP_LIB"] = os.path.join(ROOT, "ab", "libpfac_hip_trace.so")
+os.environ["PFAC_HIP_LIB"] = os.path.join(ROOT, "abx", "libpfac_hip_trace.so")
 import numpy as np, torch
 from phfpfac_amd import GpuMatcher, PfacTable
 DATA = os.path.join(ROOT, "tests", "golden", "data")
@@ -47,6 +47,11 @@ for b in (0, 3):
     if rows:
         ph = {"load wait + lds write": np.mean([r_[5] - r_[4] for r_ in rows]), "epoch + root/level-2": np.mean([r_[6] - r_[5] for r_ in rows]),
               "compact + walk + stage": np.mean([r_[7] - r_[6] for r_ in rows]), "post + emit": np.mean([r_[8] - r_[7] for r_ in rows])}
+        if rows[0][10]:
+            fine = {"lds write->loads issued": np.mean([r_[10] - r_[5] for r_ in rows]), "emit r-2": np.mean([r_[11] - r_[10] for r_ in rows]),
+                    "root half0": np.mean([r_[12] - r_[11] for r_ in rows]), "level2 half0": np.mean([r_[13] - r_[12] for r_ in rows]),
+                    "root half1": np.mean([r_[14] - r_[13] for r_ in rows]), "level2 half1": np.mean([r_[6] - r_[14] for r_ in rows])}
+            print("  classification, fine (us):", {k: round(v / 100, 2) for k, v in fine.items()})
         per = np.mean(np.diff([x[r, 4] for r in range(4, 60) if x[r, 4]]))
         print("  wave 0 mean phases (us):", {k: round(v / 100, 2) for k, v in ph.items()}, "round", round(per / 100, 2))
 
