@@ -265,6 +265,17 @@ int pfac_records_expand(pfac_ctx *ctx, int slot, const void *d_records, uint64_t
 int pfac_records_d2h_packed(pfac_ctx *ctx, int slot, const void *d_records, void *host_words, uint64_t n_words,
                             uint64_t *host_tile_index);
 
+/* GPU-side text emitter -- the fprintf loop of main.cc:335-350 run on the device: the records of the slot's last finished
+ * scan -> the lines "At position %4d, match pattern %d\n" (position = base + pos, pattern = idmap[state] of the uploaded
+ * table), in the reference's output order, into a device buffer the slot owns; *n_bytes = their total size.  Line length
+ * depends on the digit counts: one kernel sizes the lines per 64 tiles, a prefix sum places them, a third formats -- the
+ * host only copies finished text (pfac_text_d2h, asynchronous on the slot's stream; pfac_slot_sync completes it) and
+ * write()s it.  base + 2^32 must stay below 10^18.  Byte-identical to pfac_emit_records / pfac_emit_packed.
+ * (Character-class tables, whose final states may stand for several patterns, print on the host: pfac_emit_records_multi.) */
+int pfac_emit_text_device(pfac_ctx *ctx, int slot, const void *d_records, uint64_t base, uint64_t *n_bytes);
+int pfac_text_d2h(pfac_ctx *ctx, int slot, void *host, uint64_t first, uint64_t n_bytes);
+void *pfac_slot_text(pfac_ctx *ctx, int slot);            /* device pointer of that text (valid until the slot's next pfac_emit_text_device) */
+
 /* The compact form handed to a consumer that STAYS ON THE DEVICE (the RCCL record gather sends it: 2 or 4 bytes per
  * match plus 8 bytes per 4 KiB tile over xGMI instead of 8-byte pfac_records): the n_tiles entries of the slot's tile
  * index -> d_tile_index_out and, unless d_words_out is NULL or the record heap itself, heap words [0, n_words) ->

@@ -83,6 +83,7 @@ HIP_SYMBOLS = (
     "pfac_scan_finish", "pfac_scan_elapsed_ms", "pfac_records_d2h", "pfac_slot_sync", "pfac_records_checksum",
     "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_scan_staging", "pfac_trace_table_compat", "pfac_scan_format",
     "pfac_records_expand", "pfac_records_d2h_packed", "pfac_scan_capacity_hint", "pfac_records_packed_device",
+    "pfac_emit_text_device", "pfac_text_d2h", "pfac_slot_text",
 )
 
 _host = None
@@ -180,6 +181,10 @@ def hip_lib() -> C.CDLL:
         L.pfac_records_expand.argtypes = [vp, i, vp, u64, u64, vp]
         L.pfac_records_d2h_packed.argtypes = [vp, i, vp, vp, u64, vp]
         L.pfac_records_packed_device.argtypes = [vp, i, vp, vp, u64, vp]
+        L.pfac_emit_text_device.argtypes = [vp, i, vp, u64, C.POINTER(u64)]
+        L.pfac_text_d2h.argtypes = [vp, i, vp, u64, u64]
+        L.pfac_slot_text.argtypes = [vp, i]
+        L.pfac_slot_text.restype = vp
         L.pfac_slot_sync.argtypes = [vp, i]
         L.pfac_records_checksum.argtypes = [vp, i, vp, u64, u64, C.POINTER(u64)]
         L.pfac_fill_tiled.argtypes = [vp, i, vp, u64, vp, C.c_uint32, u64]

@@ -1628,6 +1628,7 @@ __global__ void pfac_scan_groups_kernel(unsigned long long *gsum, unsigned n_gro
     __syncthreads();
     unsigned long long acc = part[threadIdx.x];
     for (unsigned i = lo; i < hi; i++) { const unsigned long long v = gsum[i]; gsum[i] = acc; acc += v; }
+    if (hi == n_groups && lo < hi) gsum[n_groups] = acc;       // (the thread that owns the last group: the grand total)
 }
 // records [first, first + n) of the sorted sequence -> out[0, n)
 template <int BYTES>
@@ -1654,6 +1655,134 @@ __global__ void pfac_expand_kernel(const void *rec, const unsigned long long *ti
             pfac_record o;
             heap_record<BYTES>(rec, tlo + i, (unsigned long long)g * XGROUP + j, o.pos, o.state);
             out[k - first] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GPU-side text emitter (replaces the fprintf loop of main.cc:335-350 on the device): the compact records of a scan ->
+// the lines  "At position %4d, match pattern %d\n"  in output order, in one device buffer.  Three kernels: bytes per
+// group of 64 tiles (line length depends on the digit counts), exclusive scan of the group sums (pfac_scan_groups_kernel),
+// format.  The host only copies the finished text and write()s it.
+__device__ __forceinline__ unsigned ndigits32(unsigned v) {
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) +
+           (v >= 100000000u) + (v >= 1000000000u);
+}
+__device__ __forceinline__ unsigned ndigits64(unsigned long long v) {       // v < 10^18
+    return v < 1000000000ull ? ndigits32((unsigned)v) : 9u + ndigits32((unsigned)(v / 1000000000ull));
+}
+__device__ __forceinline__ unsigned text_line_len(unsigned long long pos, unsigned id) {
+    const unsigned dp = ndigits64(pos);
+    return 12u + (dp < 4u ? 4u : dp) + 16u + ndigits32(id) + 1u;
+}
+constexpr int TEXT_LINE_MAX = 12 + 18 + 16 + 10 + 1;          // positions below 10^18, ids below 2^32
+constexpr int TEXT_IMG = 16 + WAVE * TEXT_LINE_MAX + 15;       // LDS image of one chunk of 64 lines, congruent mod 16 with its place in the text
+
+// bytes of text per group of XGROUP tiles (lane j of a wave: tile g * 64 + j; its records by all lanes in turn)
+template <int BYTES>
+__global__ void pfac_text_size_kernel(const void *rec, const unsigned long long *tix, unsigned long long n_tiles, unsigned long long cap,
+                                      unsigned long long base, const int *idmap, unsigned long long *gsum, unsigned n_groups) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const unsigned long long t = (unsigned long long)g * XGROUP + lane;
+    const unsigned long long e = t < n_tiles ? tix[t] : 0ull;
+    const unsigned c = (unsigned)(e >> TIX_CNT_SHIFT);
+    const unsigned long long lo = e & TIX_BASE_MASK;
+    unsigned long long total = 0;
+    for (int j = 0; j < XGROUP; j++) {
+        const unsigned tc = __shfl(c, j, WAVE);
+        if (tc == 0) continue;
+        const unsigned long long tlo = __shfl(lo, j, WAVE);
+        unsigned long long sum = 0;
+        for (unsigned i = (unsigned)lane; i < tc && tlo + i < cap; i += WAVE) {
+            unsigned pos, st;
+            heap_record<BYTES>(rec, tlo + i, (unsigned long long)g * XGROUP + j, pos, st);
+            sum += text_line_len(base + pos, (unsigned)idmap[st]);
+        }
+        total += sum;                                          // (per lane; summed over the wave once, below)
+    }
+    total = wave_sum64(total);
+    if (lane == 0) gsum[g] = total;
+}
+
+// decimal digits of v (nd of them, most significant first) to p[0..nd)
+__device__ __forceinline__ void put_digits32(unsigned char *p, unsigned v, unsigned nd) {
+    for (unsigned k = nd; k-- > 0;) { const unsigned q = v / 10u; p[k] = (unsigned char)('0' + (v - q * 10u)); v = q; }
+}
+
+template <int BYTES>
+__global__ __launch_bounds__(256) void pfac_text_format_kernel(const void *rec, const unsigned long long *tix, unsigned long long n_tiles,
+                                                               unsigned long long cap, unsigned long long base, const int *idmap,
+                                                               const unsigned long long *gpre, unsigned n_groups, unsigned char *text) {
+    __shared__ __attribute__((aligned(16))) unsigned char img_all[4][(TEXT_IMG + 15) / 16 * 16];
+    const int lane = threadIdx.x & (WAVE - 1);
+    unsigned char *img = img_all[threadIdx.x >> 6];
+    const unsigned g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const unsigned long long t = (unsigned long long)g * XGROUP + lane;
+    const unsigned long long e = t < n_tiles ? tix[t] : 0ull;
+    const unsigned c = (unsigned)(e >> TIX_CNT_SHIFT);
+    const unsigned long long lo = e & TIX_BASE_MASK;
+    unsigned long long at = gpre[g];                           // text offset of the next line (wave-uniform)
+    for (int j = 0; j < XGROUP; j++) {
+        const unsigned tc = __shfl(c, j, WAVE);
+        if (tc == 0) continue;
+        const unsigned long long tlo = __shfl(lo, j, WAVE);
+        for (unsigned c0 = 0; c0 < tc; c0 += WAVE) {           // a chunk of up to 64 lines
+            const unsigned i = c0 + (unsigned)lane;
+            const bool have = i < tc && tlo + i < cap;
+            unsigned pos = 0, st = 0, id = 0, len = 0, dp = 0, di = 0;
+            unsigned long long gp = 0;
+            if (have) {
+                heap_record<BYTES>(rec, tlo + i, (unsigned long long)g * XGROUP + j, pos, st);
+                id = (unsigned)idmap[st];
+                gp = base + pos;
+                dp = ndigits64(gp);
+                di = ndigits32(id);
+                len = 12u + (dp < 4u ? 4u : dp) + 16u + di + 1u;
+            }
+            const unsigned incl = wave_incl_scan(len);
+            const unsigned total = bcast_last(incl);
+            const unsigned a0 = (unsigned)(at & 15ull);        // the image starts at the 16-byte block the chunk's first byte lies in
+            if (have) {
+                unsigned char *p = img + a0 + (incl - len);
+                const char *h = "At position ";
+#pragma unroll
+                for (int k = 0; k < 12; k++) p[k] = (unsigned char)h[k];
+                p += 12;
+                for (unsigned k = dp; k < 4u; k++) *p++ = ' ';                               // %4d
+                if (gp < 1000000000ull) put_digits32(p, (unsigned)gp, dp);
+                else {
+                    const unsigned hi = (unsigned)(gp / 1000000000ull), lo9 = (unsigned)(gp - (unsigned long long)hi * 1000000000ull);
+                    put_digits32(p, hi, dp - 9u);
+                    put_digits32(p + (dp - 9u), lo9, 9u);
+                }
+                p += dp;
+                const char *m = ", match pattern ";
+#pragma unroll
+                for (int k = 0; k < 16; k++) p[k] = (unsigned char)m[k];
+                p += 16;
+                put_digits32(p, id, di);
+                p[di] = (unsigned char)'\n';
+            }
+            wave_lds_sync();
+            // image bytes [a0, a0 + total) -> text[at, at + total): whole 16-byte blocks with one store per lane, the ragged
+            // first and last block byte by byte (their other bytes belong to the neighbouring chunks)
+            unsigned char *dst = text + (at - a0);            // 16-byte aligned (the text buffer is)
+            const unsigned end = a0 + total;
+            const unsigned b_lo = a0 ? 16u : 0u, b_hi = end & ~15u;   // full blocks cover [b_lo, b_hi)
+            if (b_hi > b_lo) {
+                for (unsigned o = b_lo + 16u * (unsigned)lane; o < b_hi; o += 16u * WAVE)
+                    __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(img + o), reinterpret_cast<u32x4 *>(dst + o));
+                if (a0 && (unsigned)lane < 16u - a0) dst[a0 + lane] = img[a0 + lane];
+                if ((unsigned)lane < end - b_hi) dst[b_hi + lane] = img[b_hi + lane];
+            } else {
+                // no whole block: at most 31 bytes (e.g. one short line): byte by byte
+                if (a0 + (unsigned)lane < end) dst[a0 + lane] = img[a0 + lane];
+            }
+            wave_lds_sync();
+            at += total;
         }
     }
 }
@@ -1703,8 +1832,10 @@ struct Slot {
     uint64_t record_cap = 0;
     unsigned long long *d_tile_index = nullptr;   // per tile of the last scan: first record | count << 40
     uint64_t tile_cap = 0;
-    unsigned long long *d_gsum = nullptr; // scratch of the expand path: record prefix per group of 64 tiles
+    unsigned long long *d_gsum = nullptr; // scratch of the expand / text paths: record (byte) prefix per group of 64 tiles (+ the total)
     uint64_t gsum_cap = 0;
+    unsigned char *d_text = nullptr;      // pfac_emit_text_device: the formatted lines of the slot's last scan
+    uint64_t text_cap = 0, text_bytes = 0;
     pfac_record *d_wide = nullptr;        // scratch of pfac_records_d2h: packed records expanded on the device
     uint64_t wide_cap = 0;
     int last_rec_bytes = 4;               // record form of the slot's last scan (2, 4 or 8 bytes)
@@ -2201,6 +2332,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
         if (s.d_ctl) (void)hipFree(s.d_ctl);
         if (s.d_tile_index) (void)hipFree(s.d_tile_index);
         if (s.d_gsum) (void)hipFree(s.d_gsum);
+        if (s.d_text) (void)hipFree(s.d_text);
         if (s.d_wide) (void)hipFree(s.d_wide);
         if (s.d_dbg) (void)hipFree(s.d_dbg);
         if (s.d_sum) (void)hipFree(s.d_sum);
@@ -2456,6 +2588,15 @@ int pfac_scan_elapsed_ms(pfac_ctx *ctx, int slot, float *ms) {
 
 // Records [first, first+n) of the slot's last scan, in (position, pattern length) order -> pfac_record at d_out
 // (device), on the slot's stream: prefix over the tile index, then a copy out of the heap.
+static int ensure_gsum(pfac_ctx *ctx, Slot &s, unsigned n_groups) {       // n_groups prefixes + the grand total behind them
+    if ((uint64_t)n_groups + 1 <= s.gsum_cap) return PFAC_OK;
+    if (s.d_gsum) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_gsum)); s.d_gsum = nullptr; }
+    const uint64_t cap = n_groups < 4096 ? 4097 : (uint64_t)n_groups + n_groups / 4 + 1;
+    HIP_TRY(ctx, hipMalloc((void **)&s.d_gsum, cap * 8));
+    s.gsum_cap = cap;
+    return PFAC_OK;
+}
+
 static int expand_records(pfac_ctx *ctx, Slot &s, const void *src, uint64_t first, uint64_t n, pfac_record *d_out) {
     // records that do not exist, or that the last scan could not write, are never delivered as if they did: the copy
     // kernel skips them and the caller would read whatever its buffer held before
@@ -2464,12 +2605,8 @@ static int expand_records(pfac_ctx *ctx, Slot &s, const void *src, uint64_t firs
     if (s.last_used > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "the slot's last scan overflowed its record heap: scan again with a larger one");
     if (n == 0 || s.last_tiles == 0) return PFAC_OK;
     const unsigned n_groups = (unsigned)((s.last_tiles + XGROUP - 1) / XGROUP);
-    if (n_groups > s.gsum_cap) {
-        if (s.d_gsum) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_gsum)); s.d_gsum = nullptr; }
-        const uint64_t cap = n_groups < 4096 ? 4096 : n_groups + n_groups / 4;
-        HIP_TRY(ctx, hipMalloc((void **)&s.d_gsum, cap * 8));
-        s.gsum_cap = cap;
-    }
+    int rc = ensure_gsum(ctx, s, n_groups);
+    if (rc) return rc;
     const unsigned gblocks = (n_groups + 3) / 4;           // four waves (groups) per 256-thread block
     hipLaunchKernelGGL(pfac_tix_group_sum_kernel, dim3(gblocks), dim3(256), 0, s.stream, s.d_tile_index,
                        (unsigned long long)s.last_tiles, s.d_gsum, n_groups);
@@ -2566,6 +2703,62 @@ int pfac_records_packed_device(pfac_ctx *ctx, int slot, const void *d_records, v
     if (s.last_tiles) HIP_TRY(ctx, hipMemcpyAsync(d_tile_index_out, s.d_tile_index, s.last_tiles * 8, hipMemcpyDeviceToDevice, s.stream));
     return PFAC_OK;
 }
+
+int pfac_emit_text_device(pfac_ctx *ctx, int slot, const void *d_records, uint64_t base, uint64_t *n_bytes) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!n_bytes) return fail(ctx, PFAC_E_ARG, "null argument");
+    *n_bytes = 0;
+    if (!ctx->have_table) return fail(ctx, PFAC_E_STATE, "no table uploaded");
+    Slot &s = ctx->slots[slot];
+    const void *src = d_records ? d_records : s.d_records;
+    if (!s.scanned || s.pending) return fail(ctx, PFAC_E_STATE, "pfac_emit_text_device needs a finished scan");
+    if (s.last_used > s.last_cap) return fail(ctx, PFAC_E_OVERFLOW, "the slot's last scan overflowed its record heap: scan again with a larger one");
+    if (base + (1ull << 32) >= 1000000000000000000ull) return fail(ctx, PFAC_E_ARG, "pfac_emit_text_device: positions must stay below 10^18");
+    s.text_bytes = 0;
+    if (s.last_total == 0 || s.last_tiles == 0) return PFAC_OK;
+    if (!src) return fail(ctx, PFAC_E_ARG, "null record buffer");
+    USE_DEVICE(ctx);
+    const unsigned n_groups = (unsigned)((s.last_tiles + XGROUP - 1) / XGROUP);
+    rc = ensure_gsum(ctx, s, n_groups);
+    if (rc) return rc;
+    const unsigned gblocks = (n_groups + 3) / 4;           // four waves (groups of 64 tiles) per 256-thread block
+    auto sk = s.last_rec_bytes == 2 ? pfac_text_size_kernel<2> : (s.last_rec_bytes == 4 ? pfac_text_size_kernel<4> : pfac_text_size_kernel<8>);
+    hipLaunchKernelGGL(sk, dim3(gblocks), dim3(256), 0, s.stream, src, s.d_tile_index, (unsigned long long)s.last_tiles,
+                       (unsigned long long)s.last_cap, (unsigned long long)base, ctx->d_idmap, s.d_gsum, n_groups);
+    hipLaunchKernelGGL(pfac_scan_groups_kernel, dim3(1), dim3(1024), 0, s.stream, s.d_gsum, n_groups);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, s.d_gsum + n_groups, 8, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    if (total + 32 > s.text_cap) {
+        if (s.d_text) { HIP_TRY(ctx, hipFree(s.d_text)); s.d_text = nullptr; s.text_cap = 0; }
+        const uint64_t cap = total + total / 8 + 4096;
+        HIP_TRY(ctx, hipMalloc((void **)&s.d_text, cap));
+        s.text_cap = cap;
+    }
+    auto fk = s.last_rec_bytes == 2 ? pfac_text_format_kernel<2> : (s.last_rec_bytes == 4 ? pfac_text_format_kernel<4> : pfac_text_format_kernel<8>);
+    hipLaunchKernelGGL(fk, dim3(gblocks), dim3(256), 0, s.stream, src, s.d_tile_index, (unsigned long long)s.last_tiles,
+                       (unsigned long long)s.last_cap, (unsigned long long)base, ctx->d_idmap, s.d_gsum, n_groups, s.d_text);
+    HIP_TRY(ctx, hipGetLastError());
+    s.text_bytes = total;
+    *n_bytes = total;
+    return PFAC_OK;
+}
+
+int pfac_text_d2h(pfac_ctx *ctx, int slot, void *host, uint64_t first, uint64_t n) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    Slot &s = ctx->slots[slot];
+    if (first + n > s.text_bytes) return fail(ctx, PFAC_E_ARG, "pfac_text_d2h: range exceeds the text of the slot's last pfac_emit_text_device");
+    if (n == 0) return PFAC_OK;
+    if (!host) return fail(ctx, PFAC_E_ARG, "null buffer");
+    USE_DEVICE(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(host, s.d_text + first, n, hipMemcpyDeviceToHost, s.stream));
+    return PFAC_OK;
+}
+
+void *pfac_slot_text(pfac_ctx *ctx, int slot) { return check_slot(ctx, slot) ? nullptr : ctx->slots[slot].d_text; }
 
 int pfac_slot_sync(pfac_ctx *ctx, int slot) {
     int rc = check_slot(ctx, slot);

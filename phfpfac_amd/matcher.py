@@ -203,6 +203,20 @@ class GpuMatcher:
                                                        _ptr(d_tile_index_out)))
         return rb, nt, used
 
+    def emit_text_device(self, base: int = 0, slot: int = 0, d_records=None) -> int:
+        """Format the slot's last finished scan into ``GPU_match_result.txt`` lines ON THE GPU (main.cc:335-350); returns
+        the byte count.  ``text_to_host`` fetches them."""
+        n = C.c_uint64(0)
+        self._check(self._L.pfac_emit_text_device(self._ctx, slot, _ptr(d_records), int(base), C.byref(n)))
+        return n.value
+
+    def text_to_host(self, n_bytes: int, slot: int = 0, first: int = 0) -> bytes:
+        out = np.empty(int(n_bytes), dtype=np.uint8)
+        if n_bytes:
+            self._check(self._L.pfac_text_d2h(self._ctx, slot, out.ctypes.data, int(first), int(n_bytes)))
+            self.sync(slot)
+        return out.tobytes()
+
     def checksum(self, n: int, base: int = 0, slot: int = 0, d_records=None) -> int:
         s = C.c_uint64(0)
         self._check(self._L.pfac_records_checksum(self._ctx, slot, _ptr(d_records), int(n), int(base), C.byref(s)))

@@ -944,3 +944,97 @@ def test_dense_depth1_rows_by_column(n_first, n_second, force_l2, tmp_path, monk
     pos, ids = oracle_pairs(str(pf), data)
     assert pos.size > 3000
     assert_same(table, rec, pos, ids)
+
+
+# ---------------------------------------------------------------------------
+# round 3: the GPU-side text emitter (main.cc:335-350 on the device)
+
+@pytest.mark.parametrize("case", sorted(FP["cases"]))
+def test_gpu_text_emitter_goldens(case, resolve):
+    """pfac_emit_text_device: the lines of GPU_match_result.txt formatted ON THE GPU from the compact record heap + tile
+    index (sizes per 64 tiles, prefix sum, format), copied back as finished text: md5-identical to the reference's file
+    for every golden case."""
+    c = FP["cases"][case]
+    table = PfacTable.from_file(resolve(c["pattern"]), c["width"])
+    data = np.frombuffer(open(resolve(c["input"]), "rb").read()[:-1], dtype=np.uint8)     # main.cc:138
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        g.reserve(0, max(data.size, 1), max(data.size // 2, 4096))
+        if data.size:
+            g.h2d(data, 0)
+        n = g.scan_resident(data.size, data.size)
+        nbytes = g.emit_text_device(0)
+        text = g.text_to_host(nbytes)
+    assert n == c["lines"] and nbytes == len(text) == c["bytes"]
+    assert hashlib.md5(text).hexdigest() == c["md5"]
+
+
+@pytest.mark.parametrize("base,knob", [(0, {}), (999_999_000, {}), (5 << 32, {}), (10**17, {}), (9_990, {"PFAC_WIDE": "1"}),
+                                       (99_999_999_000, {"PFAC_DENSE": "1"})])
+def test_gpu_text_emitter_digit_boundaries_and_record_forms(base, knob, resolve, tmp_path, monkeypatch):
+    """Line length changes with the digit count of the position (%4d pads to 4, grows to 18 digits) and of the pattern
+    id: bases that put 10^k boundaries inside the scanned range, the 8-byte record form (PFAC_WIDE), dense staging;
+    sparse tiles (chunks of a few lines) and dense ones (hundreds of lines per tile).  Must equal the host emitter's
+    bytes, which the goldens pin."""
+    for k, v in knob.items():
+        monkeypatch.setenv(k, v)
+    para = open(resolve("paragraph402"), "rb").read()
+    data = tiled_bytes(300_001, para)
+    data[100_000:101_000] = 0                                   # a stretch without matches: empty tiles, tiny chunks
+    table = PfacTable.from_file(resolve("xaa"), 256)
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        rec = g.scan_bytes(data)
+        nbytes = g.emit_text_device(base)
+        text = g.text_to_host(nbytes)
+        assert g.text_to_host(min(nbytes, 1000), first=max(nbytes - 1000, 0)) == text[-1000:]
+        with pytest.raises(PfacError):
+            g.text_to_host(nbytes + 1)
+    out = tmp_path / "host.txt"
+    assert emit_records(str(out), rec, table.idmap, base=base) == nbytes
+    assert out.read_bytes() == text
+
+
+def test_gpu_text_emitter_at_size(resolve):
+    """1 GiB x experimentpattern (80.1 M lines, 3.1 GB of text): byte count from the closed form of the periodic input,
+    head and tail of the text against the host emitter, a checksum of the whole text against the multi-threaded host
+    emitter's file."""
+    import torch
+    para = open(resolve("paragraph402"), "rb").read()
+    N = 1 << 30
+    table = PfacTable.from_file(resolve("experimentpattern"), 256)
+    with GpuMatcher(0, 1) as g:
+        g.load_table(table)
+        buf = torch.empty(N + 1024, dtype=torch.uint8, device="cuda:0")
+        g.fill_tiled(buf, N, para)
+        g.reserve(0, 0, N // 8)
+        n = g.scan_resident(N, N, d_input=buf)
+        nbytes = g.emit_text_device(0)
+        # expected size: every record is one line; digits(pos) from the record positions themselves (host, vectorised)
+        head = g.text_to_host(1 << 20)
+        tail = g.text_to_host(1 << 20, first=nbytes - (1 << 20))
+        k = head.count(b"\n")
+        rec_head = g.records_to_host(k + 1)
+        rec_tail_n = tail.count(b"\n")
+        rec_tail = g.records_to_host(rec_tail_n, first=n - rec_tail_n)
+    want_head = "".join("At position %4d, match pattern %d\n" % (p, i) for p, i in zip(rec_head["pos"][:k], table.idmap[rec_head["state"][:k]]))
+    assert head.decode().startswith(want_head) and len(want_head) > (1 << 20) - 64
+    want_tail = "".join("At position %4d, match pattern %d\n" % (p, i) for p, i in zip(rec_tail["pos"], table.idmap[rec_tail["state"]]))
+    assert tail.decode().endswith(want_tail) and tail.endswith(b"\n")
+    # the total, exactly: the input has period 402, so the match set is {off + 402 q} for the (offset, pattern) pairs of one
+    # period, cut where a match would cross N; a line is 12 + max(4, digits(pos)) + 16 + digits(id) + 1 bytes
+    win = tiled_bytes(402 * 8, para)
+    pos, ids = oracle_pairs(resolve("experimentpattern"), win)
+    sel = (pos >= 402) & (pos < 804)
+    plen = {i + 1: len(l) for i, l in enumerate(open(resolve("experimentpattern"), "rb").read().split(b"\n")[:-1])}
+    total = lines = 0
+    for off, pid in zip(pos[sel] - 402, ids[sel]):
+        q_max = (N - plen[int(pid)] - int(off)) // 402          # last q with off + 402 q + len <= N
+        for d in range(4, 11):
+            lo, hi = (0 if d == 4 else 10 ** (d - 1)), 10 ** d     # positions with this many printed digits
+            q_lo = max(0, -(-(lo - int(off)) // 402))
+            q_hi = min(q_max, (hi - 1 - int(off)) // 402)
+            c = max(0, q_hi - q_lo + 1)
+            lines += c
+            total += c * (12 + d + 16 + len(str(int(pid))) + 1)
+    assert lines == n and total == nbytes
