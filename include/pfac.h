@@ -222,6 +222,9 @@ int pfac_slot_set_stream(pfac_ctx *ctx, int slot, void *stream_handle);
 /* Async H2D of input bytes into the slot's input buffer at dst_offset
  * (cudaMemcpy H2D, master_kernel.cu:359, made asynchronous on the slot's stream). */
 int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, uint64_t dst_offset);
+/* Block until the slot's last pfac_slot_h2d has left the host buffer (which may then be refilled while the scan that
+ * follows it on the stream is still running): what lets a reader pool run ahead of the copies. */
+int pfac_slot_h2d_wait(pfac_ctx *ctx, int slot);
 
 /*
  * The scan: replaces the kernel launch of GPU_TraceTable (master_kernel.cu:396-423).

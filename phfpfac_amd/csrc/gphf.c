@@ -11,29 +11,36 @@
  * What differs underneath (all through the C-ABI of include/pfac.h):
  *   - ONE automaton for the whole pattern file; the INPUT is cut into chunks
  *     (owned bytes + max_pat_len-1 bytes of halo) that are dealt round-robin
- *     to the visible GPUs, instead of the pattern set being partitioned
- *     (create_table_reorder.c:217-247);
- *   - streaming ingest: each GPU worker pread()s its next chunk into a pinned
- *     staging buffer of its pipeline slot, so the file is never resident as a
- *     whole (the reference reads it all into one cudaHostAlloc buffer,
- *     main.cc:147-155) and inputs larger than host RAM work;
+ *     to the workers (one per visible GPU), instead of the pattern set being
+ *     partitioned (create_table_reorder.c:217-247);
+ *   - streaming ingest: a POOL of reader threads pread()s the chunks, piece by
+ *     piece, into pinned staging buffers AHEAD of the copies (a worker has one
+ *     staging buffer more than pipeline slots; a buffer is refilled as soon as
+ *     its H2D copy has left it), so the file is never resident as a whole (the
+ *     reference reads it all into one cudaHostAlloc buffer, main.cc:147-155),
+ *     inputs larger than host RAM work, and page-cache reads, H2D copies and
+ *     scans overlap;
  *   - <streamnum> really is the number of pipeline slots per GPU: chunk k+1 is
- *     read and copied H2D while chunk k is scanned and chunk k-1's records
- *     return (the reference creates streams, main.cc:209, and never uses them);
- *   - results come back as compact records -- 4 bytes per match plus 8 bytes per
- *     4 KiB of input (the tile index that orders them) -- not as a dense
- *     input_size x max_pat_len array (master_kernel.cu:235-236,428); an emitter
- *     thread prints finished chunks straight from that form, in input order,
- *     while later ones are still being scanned, so memory stays bounded.
+ *     copied H2D while chunk k is scanned and chunk k-1's results return (the
+ *     reference creates streams, main.cc:209, and never uses them);
+ *   - the device contexts are created while the host still builds the table;
+ *   - results: the GPU FORMATS the text itself (pfac_emit_text_device: the
+ *     fprintf loop of main.cc:341-349 as three kernels); finished text comes
+ *     back through a ring of pinned buffers and a pool of writer threads
+ *     pwrite()s it at offsets the chunk order fixes.  PFAC_EMIT=host selects
+ *     the host formatter instead (compact records -- 2 or 4 bytes per match
+ *     plus 8 bytes per 4 KiB tile -- D2H, printed in chunk order by
+ *     pfac_emit_packed on several threads).
  * There is no CPU matching path in this program: without a GPU it fails.
  *
  * Environment: PFAC_GPUS=n limits the number of GPUs used; PFAC_WORKERS_PER_GPU=m runs m independent workers (host
  * thread + context + pipeline slots each) on every GPU -- the chunks are dealt round-robin over all n * m workers, so the
- * multi-worker dealing and the shared in-order emitter can be exercised on a single device; PFAC_CHUNK_MB sets
- * the chunk size (default 64); PFAC_EMIT_THREADS the emitter's formatter threads;
- * PFAC_READ_THREADS the threads that pread() one chunk (default: cores / GPUs, at most 8).
+ * multi-worker dealing and the shared in-order output can be exercised on a single device; PFAC_CHUNK_MB sets the chunk
+ * size (default 32); PFAC_READ_THREADS the size of the reader pool (default: cores, at most 16); PFAC_EMIT=host|device;
+ * PFAC_EMIT_THREADS the host formatter's / the writer pool's threads.
  */
 #define _FILE_OFFSET_BITS 64
+#define _GNU_SOURCE
 #include "pfac.h"
 
 #include <fcntl.h>
@@ -48,26 +55,42 @@
 typedef struct {
     uint64_t base;          /* global offset of the chunk's first owned byte */
     uint64_t n_owned, n_avail;
-    pfac_record *rec;       /* host copy of the chunk's records: 8-byte form (automata beyond 2^20 final states) ... */
+    /* host formatter: host copy of the chunk's records: 8-byte form (automata beyond 2^20 final states) ... */
+    pfac_record *rec;
     void *words;            /* ... or the compact form: record heap (16- or 32-bit words) + tile index (pfac.h) */
     int word_bytes;
     uint64_t *tix;
     uint64_t n_tiles;
     uint64_t n_words;       /* heap words copied back (pfac_scan_format's *used) */
     uint64_t n_rec;
-    int done;               /* guarded by g_mu */
+    /* device formatter: bytes of text this chunk prints, and where they go in the file */
+    uint64_t text_bytes, text_off;
+    int sized;              /* text_bytes is known          (guarded by g_mu) */
+    int done;               /* results handed over          (guarded by g_mu) */
 } chunk_t;
 
+enum { ST_UNALLOC = 0, ST_FREE, ST_READING, ST_READY, ST_INFLIGHT };
 typedef struct {
-    int index, device, n_gpu, n_streams;    /* worker `index` of n_gpu workers (the name is historical: workers, not devices), on GPU `device` */
-    const int32_t *blob;
-    size_t blob_words;
+    void *buf;              /* pinned: chunk_bytes + the longest halo */
+    int state;              /* guarded by g_mu */
+    int pieces_left;
+    int io_error;
+} stage_t;
+
+typedef struct worker {
+    int index, device, n_workers, n_streams;
     int fd;                         /* input file */
-    uint64_t chunk_bytes, halo;
-    chunk_t *chunks;                /* all chunks; this worker takes k = device, device + n_gpu, ... */
-    int n_chunks;
-    int read_threads;               /* threads that pread() one chunk into the pinned staging buffer */
-    double kernel_ms, setup_ms, read_ms, drain_ms;   /* where this worker's wall time went */
+    uint64_t chunk_bytes;
+    chunk_t *chunks;                /* all chunks; this worker takes k = index, index + n_workers, ... */
+    int n_chunks, n_mine;
+    stage_t *stage;
+    int n_stage;
+    int next_read;                  /* ordinal (among this worker's chunks) of the next chunk to hand to the readers */
+    uint64_t piece;
+    int emit_device;
+    int out_fd;
+    double kernel_ms, setup_ms, table_wait_ms, read_wait_ms, drain_ms, text_ms;   /* where this worker's wall time went */
+    uint64_t matches;
     int internal_retries;           /* scans repeated after PFAC_E_INTERNAL (a protocol timeout: a bug, reported, never hidden) */
     int rc;
     char err[256];
@@ -75,9 +98,16 @@ typedef struct {
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;
-static int g_emitted = 0;           /* chunks the emitter has consumed */
-static int g_window = 0;            /* a worker may run at most this many chunks ahead of the emitter */
+static int g_emitted = 0;           /* chunks whose results have left the pipeline, in order */
+static int g_window = 0;            /* a worker may run at most this many chunks ahead of that */
 static int g_failed = 0;
+/* the table, built by main() while the workers create their contexts */
+static const int32_t *g_blob = NULL;
+static size_t g_blob_words = 0;
+static int g_table_ready = 0;
+/* device formatter: file offsets are handed out in chunk order as the chunks' text sizes come in */
+static int g_next_off_chunk = 0;
+static uint64_t g_text_total = 0;
 
 static double now_ms(void) {
     struct timespec ts;
@@ -85,13 +115,17 @@ static double now_ms(void) {
     return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
 
-static int fail(worker_t *w, pfac_ctx *ctx, int rc, const char *what) {
-    snprintf(w->err, sizeof w->err, "worker %d (GPU %d): %s: %s", w->index, w->device, what, ctx ? pfac_last_error(ctx) : "");
-    w->rc = rc;
+static void set_failed(void) {
     pthread_mutex_lock(&g_mu);
     g_failed = 1;
     pthread_cond_broadcast(&g_cv);
     pthread_mutex_unlock(&g_mu);
+}
+
+static int fail(worker_t *w, pfac_ctx *ctx, int rc, const char *what) {
+    snprintf(w->err, sizeof w->err, "worker %d (GPU %d): %s: %s", w->index, w->device, what, ctx ? pfac_last_error(ctx) : "");
+    w->rc = rc;
+    set_failed();
     return rc;
 }
 
@@ -105,42 +139,181 @@ static int read_fully(int fd, void *dst, uint64_t n, uint64_t off) {
     return 0;
 }
 
-/* One chunk is read by several threads, each pread()ing a 4 KiB-aligned slice: a single thread copies
- * out of the page cache at ~5 GB/s, far below what the H2D link and the scan take. */
-typedef struct { int fd; unsigned char *dst; uint64_t n, off; int rc; } read_job;
+/* ------------------------------------------------------------------------------------------------------------
+ * Thread pool (readers and writers share the code): a job is a function and four words; FIFO. */
+typedef struct { void (*fn)(void *a, uint64_t x, uint64_t y, uint64_t z); void *a; uint64_t x, y, z; } job_t;
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv, idle_cv;
+    job_t *q;
+    size_t cap, head, count;
+    int stop, n_threads, busy;
+    pthread_t *th;
+} pool_t;
 
-static void *read_part(void *arg) {
-    read_job *j = (read_job *)arg;
-    j->rc = read_fully(j->fd, j->dst, j->n, j->off);
+static void *pool_main(void *arg) {
+    pool_t *p = (pool_t *)arg;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->count && !p->stop) pthread_cond_wait(&p->cv, &p->mu);
+        if (!p->count && p->stop) break;
+        job_t j = p->q[p->head];
+        p->head = (p->head + 1) % p->cap;
+        p->count--;
+        p->busy++;
+        pthread_mutex_unlock(&p->mu);
+        j.fn(j.a, j.x, j.y, j.z);
+        pthread_mutex_lock(&p->mu);
+        p->busy--;
+        if (!p->count && !p->busy) pthread_cond_broadcast(&p->idle_cv);
+    }
+    pthread_mutex_unlock(&p->mu);
     return NULL;
 }
 
-static int read_parallel(int fd, void *dst, uint64_t n, uint64_t off, int n_threads) {
-    enum { MAX_READERS = 32 };
-    if (n_threads > MAX_READERS) n_threads = MAX_READERS;
-    if (n_threads < 2 || n < (uint64_t)n_threads * (64u << 10)) return read_fully(fd, dst, n, off);
-    read_job job[MAX_READERS];
-    pthread_t th[MAX_READERS];
-    int started[MAX_READERS];
-    const uint64_t part = ((n + (uint64_t)n_threads - 1) / (uint64_t)n_threads + 4095) & ~4095ull;
-    int used = 0, rc = 0;
-    for (uint64_t at = 0; at < n; at += part, used++) {
-        read_job *j = &job[used];
-        j->fd = fd; j->dst = (unsigned char *)dst + at; j->off = off + at; j->rc = 0;
-        j->n = n - at < part ? n - at : part;
-        started[used] = used > 0 && pthread_create(&th[used], NULL, read_part, j) == 0;
-    }
-    for (int i = 0; i < used; i++)          /* slice 0, and any slice whose thread did not start, is read here */
-        if (!started[i]) read_part(&job[i]);
-    for (int i = 0; i < used; i++) {
-        if (started[i]) pthread_join(th[i], NULL);
-        if (job[i].rc) rc = -1;
-    }
-    return rc;
+static int pool_start(pool_t *p, int n_threads, size_t cap) {
+    memset(p, 0, sizeof *p);
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->cv, NULL);
+    pthread_cond_init(&p->idle_cv, NULL);
+    p->q = (job_t *)malloc(cap * sizeof(job_t));
+    p->th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    if (!p->q || !p->th) return -1;
+    p->cap = cap;
+    for (int i = 0; i < n_threads; i++)
+        if (pthread_create(&p->th[p->n_threads], NULL, pool_main, p) == 0) p->n_threads++;
+    return p->n_threads > 0 ? 0 : -1;
 }
 
-/* finish the chunk that occupies `slot`: wait, fetch count, (re-scan on overflow), copy records back, publish */
-static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap) {
+static void pool_push(pool_t *p, job_t j) {
+    pthread_mutex_lock(&p->mu);
+    if (p->count == p->cap) {                       /* grow (rare: the queue is sized for the pieces in flight) */
+        job_t *nq = (job_t *)malloc(2 * p->cap * sizeof(job_t));
+        for (size_t i = 0; i < p->count; i++) nq[i] = p->q[(p->head + i) % p->cap];
+        free(p->q);
+        p->q = nq; p->head = 0; p->cap *= 2;
+    }
+    p->q[(p->head + p->count) % p->cap] = j;
+    p->count++;
+    pthread_cond_signal(&p->cv);
+    pthread_mutex_unlock(&p->mu);
+}
+
+static void pool_wait_idle(pool_t *p) {
+    pthread_mutex_lock(&p->mu);
+    while (p->count || p->busy) pthread_cond_wait(&p->idle_cv, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+
+static void pool_stop(pool_t *p) {
+    pthread_mutex_lock(&p->mu);
+    p->stop = 1;
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->n_threads; i++) pthread_join(p->th[i], NULL);
+    free(p->q); free(p->th);
+}
+
+static pool_t g_readers, g_writers;
+
+/* ---- reader pool: one job = one piece of one chunk -> its place in a pinned staging buffer.  A single thread copies
+ * out of the page cache at ~5 GB/s, far below what the H2D link takes: the pieces of the chunks in flight are read by
+ * all the pool's threads, ahead of the worker that will copy them to the device. */
+static void read_piece(void *a, uint64_t stage_idx, uint64_t chunk_ord, uint64_t off) {
+    worker_t *w = (worker_t *)a;
+    stage_t *st = &w->stage[stage_idx];
+    const chunk_t *c = &w->chunks[w->index + (int)chunk_ord * w->n_workers];
+    const uint64_t n = c->n_avail - off < w->piece ? c->n_avail - off : w->piece;
+    const int rc = read_fully(w->fd, (unsigned char *)st->buf + off, n, c->base + off);
+    pthread_mutex_lock(&g_mu);
+    if (rc) st->io_error = 1;
+    if (--st->pieces_left == 0) {
+        st->state = ST_READY;
+        pthread_cond_broadcast(&g_cv);
+    }
+    pthread_mutex_unlock(&g_mu);
+}
+
+/* hand the next chunks of this worker to the readers while staging buffers are free (g_mu held; needs the chunk plan,
+ * i.e. the table's halo) */
+static void schedule_reads(worker_t *w) {
+    if (!g_table_ready || g_failed) return;
+    while (w->next_read < w->n_mine) {
+        const int b = w->next_read % w->n_stage;
+        stage_t *st = &w->stage[b];
+        if (st->state != ST_FREE) break;
+        const chunk_t *c = &w->chunks[w->index + w->next_read * w->n_workers];
+        const int pieces = (int)((c->n_avail + w->piece - 1) / w->piece);
+        st->io_error = 0;
+        st->state = ST_READING;
+        st->pieces_left = pieces;
+        for (int p = 0; p < pieces; p++) {
+            const job_t j = {read_piece, w, (uint64_t)b, (uint64_t)w->next_read, (uint64_t)p * w->piece};
+            pool_push(&g_readers, j);
+        }
+        w->next_read++;
+    }
+}
+
+/* ---- writer pool (device formatter): finished text arrives in pinned buffers; the pieces of a buffer are pwrite()n by
+ * several threads (one thread copies into the page cache at a few GB/s), the last one returns the buffer. */
+enum { TEXT_BUFS_MAX = 6 };
+#define TEXT_BUF_BYTES ((uint64_t)64 << 20)
+#define WRITE_PIECE ((uint64_t)4 << 20)
+typedef struct { void *buf; int pieces_left; int in_use; } textbuf_t;
+static textbuf_t g_tbuf[TEXT_BUFS_MAX];
+static int g_tbuf_n = 0;            /* allocated so far (lazily: a run without matches never pins any) */
+static int g_write_error = 0;
+
+static void write_piece(void *a, uint64_t fd_and_idx, uint64_t file_off, uint64_t n) {
+    textbuf_t *tb = &g_tbuf[fd_and_idx & 0xFF];
+    const int fd = (int)(fd_and_idx >> 8);
+    const unsigned char *p = (const unsigned char *)a;
+    int bad = 0;
+    while (n) {
+        ssize_t r = pwrite(fd, p, (size_t)n, (off_t)file_off);
+        if (r <= 0) { bad = 1; break; }
+        p += r; file_off += (uint64_t)r; n -= (uint64_t)r;
+    }
+    pthread_mutex_lock(&g_mu);
+    if (bad) { g_write_error = 1; g_failed = 1; }
+    if (--tb->pieces_left == 0) tb->in_use = 0;
+    pthread_cond_broadcast(&g_cv);
+    pthread_mutex_unlock(&g_mu);
+}
+
+/* a free pinned text buffer (allocating one while fewer than TEXT_BUFS_MAX exist); -1 on failure */
+static int text_buffer_acquire(void) {
+    pthread_mutex_lock(&g_mu);
+    for (;;) {
+        for (int i = 0; i < g_tbuf_n; i++)
+            if (!g_tbuf[i].in_use && g_tbuf[i].buf) { g_tbuf[i].in_use = 1; pthread_mutex_unlock(&g_mu); return i; }
+        if (g_tbuf_n < TEXT_BUFS_MAX) {
+            const int i = g_tbuf_n++;
+            g_tbuf[i].in_use = 1;
+            pthread_mutex_unlock(&g_mu);
+            void *p = NULL;
+            if (pfac_host_alloc(&p, TEXT_BUF_BYTES)) return -1;
+            pthread_mutex_lock(&g_mu);
+            g_tbuf[i].buf = p;
+            pthread_mutex_unlock(&g_mu);
+            return i;
+        }
+        if (g_failed) { pthread_mutex_unlock(&g_mu); return -1; }
+        pthread_cond_wait(&g_cv, &g_mu);
+    }
+}
+
+static void chunk_done(chunk_t *c) {
+    pthread_mutex_lock(&g_mu);
+    c->done = 1;
+    pthread_cond_broadcast(&g_cv);
+    pthread_mutex_unlock(&g_mu);
+}
+
+/* finish the chunk that occupies `slot`: wait, fetch count, (re-scan on overflow), bring the results back, publish */
+static int drain(worker_t *w, pfac_ctx *ctx, int slot, int k, uint64_t *cap) {
+    chunk_t *c = &w->chunks[k];
     uint64_t n = 0;
     int rc = pfac_scan_finish(ctx, slot, &n);
     /* a record heap that was too small is grown and the chunk (still in the slot's input buffer) scanned again.  A
@@ -166,6 +339,46 @@ static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap
     float ms = 0;
     if (pfac_scan_elapsed_ms(ctx, slot, &ms) == 0) w->kernel_ms += ms;
     c->n_rec = n;
+    w->matches += n;
+    if (w->emit_device) {
+        /* the GPU prints: size pass + prefix sum + format (three kernels), then the text comes back in pieces */
+        const double t0 = now_ms();
+        uint64_t tb = 0;
+        if (n && (rc = pfac_emit_text_device(ctx, slot, NULL, c->base, &tb))) return fail(w, ctx, rc, "device text emitter");
+        /* file offsets go out in chunk order: this chunk's is known once every earlier chunk has reported its size */
+        pthread_mutex_lock(&g_mu);
+        c->text_bytes = tb;
+        c->sized = 1;
+        while (g_next_off_chunk < w->n_chunks && w->chunks[g_next_off_chunk].sized) {
+            w->chunks[g_next_off_chunk].text_off = g_text_total;
+            g_text_total += w->chunks[g_next_off_chunk].text_bytes;
+            g_next_off_chunk++;
+        }
+        pthread_cond_broadcast(&g_cv);
+        while (k >= g_next_off_chunk && !g_failed) pthread_cond_wait(&g_cv, &g_mu);
+        const int stop = g_failed;
+        pthread_mutex_unlock(&g_mu);
+        if (stop) return -1;
+        for (uint64_t off = 0; off < tb; off += TEXT_BUF_BYTES) {
+            const uint64_t len = tb - off < TEXT_BUF_BYTES ? tb - off : TEXT_BUF_BYTES;
+            const int bi = text_buffer_acquire();
+            if (bi < 0) return fail(w, NULL, PFAC_E_NOMEM, "pinned text buffer");
+            if ((rc = pfac_text_d2h(ctx, slot, g_tbuf[bi].buf, off, len)) || (rc = pfac_slot_sync(ctx, slot))) return fail(w, ctx, rc, "text d2h");
+            const int pieces = (int)((len + WRITE_PIECE - 1) / WRITE_PIECE);
+            pthread_mutex_lock(&g_mu);
+            g_tbuf[bi].pieces_left = pieces;
+            pthread_mutex_unlock(&g_mu);
+            for (int p = 0; p < pieces; p++) {
+                const uint64_t po = (uint64_t)p * WRITE_PIECE, pn = len - po < WRITE_PIECE ? len - po : WRITE_PIECE;
+                const job_t j = {write_piece, (unsigned char *)g_tbuf[bi].buf + po, ((uint64_t)w->out_fd << 8) | (uint64_t)bi,
+                                 c->text_off + off + po, pn};
+                pool_push(&g_writers, j);
+            }
+        }
+        w->text_ms += now_ms() - t0;
+        chunk_done(c);
+        return 0;
+    }
     int rec_bytes = 0;
     uint64_t used = 0;
     if ((rc = pfac_scan_format(ctx, slot, &rec_bytes, &c->n_tiles, &used))) return fail(w, ctx, rc, "format");
@@ -182,19 +395,15 @@ static int drain(worker_t *w, pfac_ctx *ctx, int slot, chunk_t *c, uint64_t *cap
         if ((rc = pfac_records_d2h(ctx, slot, NULL, c->rec, 0, n))) return fail(w, ctx, rc, "d2h");
     }
     if ((rc = pfac_slot_sync(ctx, slot))) return fail(w, ctx, rc, "sync");
-    pthread_mutex_lock(&g_mu);
-    c->done = 1;
-    pthread_cond_broadcast(&g_cv);
-    pthread_mutex_unlock(&g_mu);
+    chunk_done(c);
     return 0;
 }
 
 static void *worker(void *arg) {
     worker_t *w = (worker_t *)arg;
     pfac_ctx *ctx = NULL;
-    void **stage = NULL;            /* pinned staging buffer per slot */
     uint64_t *cap = NULL;
-    int *busy = NULL;
+    int *busy = NULL;               /* chunk index occupying each slot, or -1 */
     const double ts = now_ms();
     int rc = pfac_ctx_create(w->device, w->n_streams, &ctx);
     if (rc) {
@@ -203,48 +412,82 @@ static void *worker(void *arg) {
         fail(w, NULL, rc, msg);
         return NULL;
     }
-    if ((rc = pfac_table_upload(ctx, w->blob, w->blob_words))) { fail(w, ctx, rc, "table upload"); goto out; }
-    stage = (void **)calloc((size_t)w->n_streams, sizeof(void *));
     cap = (uint64_t *)calloc((size_t)w->n_streams, sizeof(uint64_t));
     busy = (int *)malloc((size_t)w->n_streams * sizeof(int));
     for (int s = 0; s < w->n_streams; s++) busy[s] = -1;
-    for (int s = 0; s < w->n_streams; s++) {
-        if ((rc = pfac_host_alloc(&stage[s], w->chunk_bytes + w->halo + 64))) { fail(w, NULL, rc, "pinned staging buffer"); goto out; }
-        cap[s] = w->chunk_bytes / 8 + 4096;
-        if ((rc = pfac_slot_reserve(ctx, s, w->chunk_bytes + w->halo, cap[s]))) { fail(w, ctx, rc, "reserve"); goto out; }
+    /* pinned staging and device buffers need no table: sized for the longest halo a table can ask for (patterns are shorter
+     * than 1024 bytes).  The readers start on a staging buffer the moment it exists (and the chunk plan does). */
+    for (int b = 0; b < w->n_stage; b++) {
+        void *p = NULL;
+        if ((rc = pfac_host_alloc(&p, w->chunk_bytes + 1024 + 64))) { fail(w, NULL, rc, "pinned staging buffer"); goto out; }
+        pthread_mutex_lock(&g_mu);
+        w->stage[b].buf = p;
+        w->stage[b].state = ST_FREE;
+        schedule_reads(w);
+        pthread_mutex_unlock(&g_mu);
+        if (b == 0)
+            for (int s = 0; s < w->n_streams; s++) {
+                cap[s] = w->chunk_bytes / 8 + 4096;
+                if ((rc = pfac_slot_reserve(ctx, s, w->chunk_bytes + 1024, cap[s]))) { fail(w, ctx, rc, "reserve"); goto out; }
+            }
     }
     w->setup_ms = now_ms() - ts;
-    for (int j = 0, k = w->index; k < w->n_chunks && !w->rc; j++, k += w->n_gpu) {
+    {
+        const double tw = now_ms();
+        pthread_mutex_lock(&g_mu);
+        while (!g_table_ready && !g_failed) pthread_cond_wait(&g_cv, &g_mu);
+        const int stop = g_failed;
+        pthread_mutex_unlock(&g_mu);
+        if (stop) goto out;
+        w->table_wait_ms = now_ms() - tw;
+    }
+    if ((rc = pfac_table_upload(ctx, g_blob, g_blob_words))) { fail(w, ctx, rc, "table upload"); goto out; }
+    for (int j = 0; j < w->n_mine && !w->rc; j++) {
+        const int k = w->index + j * w->n_workers;
         const int slot = j % w->n_streams;
         chunk_t *c = &w->chunks[k];
         const double td = now_ms();
-        if (busy[slot] >= 0 && drain(w, ctx, slot, &w->chunks[busy[slot]], &cap[slot])) break;
+        if (busy[slot] >= 0 && drain(w, ctx, slot, busy[slot], &cap[slot])) break;
         w->drain_ms += now_ms() - td;
         busy[slot] = -1;
-        /* bounded memory: do not run further ahead of the emitter than the window */
+        /* bounded memory: do not run further ahead of the in-order output than the window; then wait for the readers */
+        const double tr = now_ms();
         pthread_mutex_lock(&g_mu);
         while (k >= g_emitted + g_window && !g_failed) pthread_cond_wait(&g_cv, &g_mu);
-        const int stop = g_failed;
+        stage_t *st = &w->stage[j % w->n_stage];
+        while (st->state != ST_READY && !g_failed) pthread_cond_wait(&g_cv, &g_mu);
+        const int stop = g_failed, ioerr = st->io_error;
+        if (!stop) st->state = ST_INFLIGHT;
         pthread_mutex_unlock(&g_mu);
+        w->read_wait_ms += now_ms() - tr;
         if (stop) break;
-        const double tr = now_ms();
-        if (read_parallel(w->fd, stage[slot], c->n_avail, c->base, w->read_threads)) { fail(w, NULL, PFAC_E_IO, "short read on the input file"); break; }
-        w->read_ms += now_ms() - tr;
-        if ((rc = pfac_slot_h2d(ctx, slot, stage[slot], c->n_avail, 0))) { fail(w, ctx, rc, "h2d"); break; }
+        if (ioerr) { fail(w, NULL, PFAC_E_IO, "short read on the input file"); break; }
+        if (c->n_avail && (rc = pfac_slot_h2d(ctx, slot, st->buf, c->n_avail, 0))) { fail(w, ctx, rc, "h2d"); break; }
         if ((rc = pfac_scan_async(ctx, slot, NULL, c->n_owned, c->n_avail, NULL, 0))) { fail(w, ctx, rc, "scan"); break; }
         busy[slot] = k;
+        /* the PREVIOUS chunk's copy has had a whole iteration: once it has left its staging buffer the readers get that
+         * buffer back (with one slot this waits for the copy just issued, which is behind it on the same stream) */
+        if (j > 0) {
+            if ((rc = pfac_slot_h2d_wait(ctx, (j - 1) % w->n_streams))) { fail(w, ctx, rc, "h2d wait"); break; }
+            pthread_mutex_lock(&g_mu);
+            w->stage[(j - 1) % w->n_stage].state = ST_FREE;
+            schedule_reads(w);
+            pthread_mutex_unlock(&g_mu);
+        }
     }
     for (int s = 0; s < w->n_streams && !w->rc; s++) {      /* drain what is still in flight, oldest first */
         int lowest = -1;
         for (int t = 0; t < w->n_streams; t++)
             if (busy[t] >= 0 && (lowest < 0 || busy[t] < busy[lowest])) lowest = t;
         if (lowest < 0) break;
-        drain(w, ctx, lowest, &w->chunks[busy[lowest]], &cap[lowest]);
+        drain(w, ctx, lowest, busy[lowest], &cap[lowest]);
         busy[lowest] = -1;
     }
 out:
-    if (stage) for (int s = 0; s < w->n_streams; s++) pfac_host_free(stage[s]);
-    free(stage); free(cap); free(busy);
+    if (w->rc) set_failed();
+    pool_wait_idle(&g_readers);     /* no reader may still write into the staging buffers freed below */
+    for (int b = 0; b < w->n_stage; b++) pfac_host_free(w->stage[b].buf);
+    free(cap); free(busy);
     pfac_ctx_destroy(ctx);
     return NULL;
 }
@@ -254,51 +497,32 @@ int main(int argc, char *argv[]) {
         fprintf(stderr, "usage: %s <pattern file name> <streamnum> <PHF width> <input file name>\n", argv[0]);
         exit(-1);
     }
+    const double t_start = now_ms();
     int streamnum = atoi(argv[2]);
     int width = atoi(argv[3]);
     if (streamnum < 1) { fprintf(stderr, "streamnum must be >= 1\n"); return 1; }
-
-    double t0 = now_ms();
-    char err[256] = "";
-    pfac_table *tab = NULL;
-    int rc = pfac_table_build_file(argv[1], width, &tab, err, sizeof err);     /* main.cc:108,125 */
-    if (rc) { fprintf(stderr, "table build failed (%d): %s\n", rc, err); return 1; }
-    double t1 = now_ms();
-    printf("state num : %d\nfinal state num : %d\nmax pattern length : %d\n", tab->state_num, tab->num_final, tab->max_pat_len);
-    printf("Number of keys    : %d\nwidth value       : %d\nr table size      : %7d\nHash table size   : %7d\n",
-           tab->n_keys, tab->width, tab->max_row, tab->ht_size);
-    size_t words = pfac_table_blob_words(tab);
-    int32_t *blob = (int32_t *)malloc(words * sizeof(int32_t));
-    if (!blob || pfac_table_to_blob(tab, blob, words)) { fprintf(stderr, "table image failed\n"); return 1; }
 
     int fd = open(argv[4], O_RDONLY);                            /* main.cc:131-139 */
     struct stat st;
     if (fd < 0 || fstat(fd, &st)) { perror("Open input file failed."); return 1; }
     uint64_t N = st.st_size > 0 ? (uint64_t)st.st_size - 1 : 0;  /* the last byte is dropped, main.cc:138 */
-    printf("input size is %llu char\n", (unsigned long long)N);
 
-    int n_gpu = 0;
+    int rc, n_gpu = 0;
     if ((rc = pfac_device_count(&n_gpu)) || n_gpu < 1) { fprintf(stderr, "no GPU available: %s\n", pfac_last_error(NULL)); return 1; }
     const char *lim = getenv("PFAC_GPUS");
     if (lim && atoi(lim) > 0 && atoi(lim) < n_gpu) n_gpu = atoi(lim);
     const int n_dev = n_gpu;
     const char *wpg = getenv("PFAC_WORKERS_PER_GPU");
     if (wpg && atoi(wpg) > 1 && atoi(wpg) <= 8) n_gpu *= atoi(wpg);      /* from here on n_gpu counts WORKERS */
-    uint64_t chunk = 64ull << 20;       /* small enough that pinning the staging buffers stays cheap, large enough to fill the GPU */
+    /* chunk size: the pipeline is bound by the host link (~55 GB/s), not by launches, so chunks stay small -- pinning the
+     * staging buffers is what a short run pays for */
+    uint64_t chunk = 32ull << 20;
     const char *cm = getenv("PFAC_CHUNK_MB");
     if (cm && atoll(cm) > 0) chunk = (uint64_t)atoll(cm) << 20;
     if (chunk > (1ull << 32)) chunk = 1ull << 32;
-    const uint64_t halo = tab->max_pat_len > 1 ? (uint64_t)tab->max_pat_len - 1 : 0;
     const int n_chunks = (int)((N + chunk - 1) / chunk);
     if (n_chunks < n_gpu) n_gpu = n_chunks > 0 ? n_chunks : 1;
     chunk_t *chunks = (chunk_t *)calloc(n_chunks > 0 ? (size_t)n_chunks : 1, sizeof(chunk_t));
-    for (int k = 0; k < n_chunks; k++) {
-        chunks[k].base = (uint64_t)k * chunk;
-        chunks[k].n_owned = chunks[k].base + chunk <= N ? chunk : N - chunks[k].base;
-        uint64_t end = chunks[k].base + chunks[k].n_owned + halo;
-        if (end > N) end = N;                                    /* walks never read past the scanned bytes */
-        chunks[k].n_avail = end - chunks[k].base;
-    }
     g_window = 2 * n_gpu * streamnum + n_gpu;
 
     const char *output_file_name = "GPU_match_result.txt";       /* main.cc:335 */
@@ -307,23 +531,75 @@ int main(int argc, char *argv[]) {
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     int emit_threads = ncpu > 16 ? 16 : (ncpu < 1 ? 1 : (int)ncpu);
     if (getenv("PFAC_EMIT_THREADS")) emit_threads = atoi(getenv("PFAC_EMIT_THREADS"));
-
-    int read_threads = (int)(ncpu / n_gpu);
-    if (read_threads > 8) read_threads = 8;
+    if (emit_threads < 1) emit_threads = 1;
+    int read_threads = ncpu > 16 ? 16 : (ncpu < 1 ? 1 : (int)ncpu);
     if (getenv("PFAC_READ_THREADS")) read_threads = atoi(getenv("PFAC_READ_THREADS"));
     if (read_threads < 1) read_threads = 1;
+    const char *em = getenv("PFAC_EMIT");
+    const int emit_device = !(em && strcmp(em, "host") == 0);
+    uint64_t piece = chunk / 4;
+    if (piece > (4ull << 20)) piece = 4ull << 20;
+    if (piece < (64ull << 10)) piece = 64ull << 10;
+    piece &= ~4095ull;
 
-    double t2 = now_ms();
+    if (pool_start(&g_readers, read_threads, 1024) || pool_start(&g_writers, emit_device ? emit_threads : 1, 256)) {
+        fprintf(stderr, "cannot start the I/O thread pools\n");
+        return 1;
+    }
+
+    /* the workers create their contexts, device buffers and pinned staging while the table is being built here */
+    const double t2 = now_ms();
     worker_t *ws = (worker_t *)calloc((size_t)n_gpu, sizeof(worker_t));
     pthread_t *th = (pthread_t *)malloc((size_t)n_gpu * sizeof(pthread_t));
     for (int g = 0; g < n_gpu; g++) {                            /* one host thread per GPU, main.cc:180-241 */
         worker_t *w = &ws[g];
-        w->index = g; w->device = g % n_dev; w->n_gpu = n_gpu; w->n_streams = streamnum; w->blob = blob; w->blob_words = words;
-        w->fd = fd; w->chunk_bytes = chunk; w->halo = halo; w->chunks = chunks; w->n_chunks = n_chunks; w->read_threads = read_threads;
-        pthread_create(&th[g], NULL, worker, w);
+        w->index = g; w->device = g % n_dev; w->n_workers = n_gpu; w->n_streams = streamnum;
+        w->fd = fd; w->chunk_bytes = chunk; w->chunks = chunks; w->n_chunks = n_chunks;
+        w->n_mine = n_chunks > g ? (n_chunks - g + n_gpu - 1) / n_gpu : 0;
+        w->n_stage = streamnum + 1;
+        w->stage = (stage_t *)calloc((size_t)w->n_stage, sizeof(stage_t));
+        w->piece = piece; w->emit_device = emit_device; w->out_fd = fileno(fpout);
     }
-    /* emitter: chunks in input order == position order; records of a chunk are already sorted */
-    uint64_t total = 0;
+    for (int g = 0; g < n_gpu; g++) pthread_create(&th[g], NULL, worker, &ws[g]);
+
+    char err[256] = "";
+    pfac_table *tab = NULL;
+    int32_t *blob = NULL;
+    const double t0 = now_ms();
+    rc = pfac_table_build_file(argv[1], width, &tab, err, sizeof err);     /* main.cc:108,125 */
+    const double t1 = now_ms();
+    size_t words = 0;
+    if (!rc) {
+        words = pfac_table_blob_words(tab);
+        blob = (int32_t *)malloc(words * sizeof(int32_t));
+        if (!blob || pfac_table_to_blob(tab, blob, words)) { rc = PFAC_E_NOMEM; snprintf(err, sizeof err, "table image failed"); }
+    }
+    if (rc) {
+        fprintf(stderr, "table build failed (%d): %s\n", rc, err);
+        set_failed();
+        for (int g = 0; g < n_gpu; g++) pthread_join(th[g], NULL);
+        return 1;
+    }
+    printf("state num : %d\nfinal state num : %d\nmax pattern length : %d\n", tab->state_num, tab->num_final, tab->max_pat_len);
+    printf("Number of keys    : %d\nwidth value       : %d\nr table size      : %7d\nHash table size   : %7d\n",
+           tab->n_keys, tab->width, tab->max_row, tab->ht_size);
+    printf("input size is %llu char\n", (unsigned long long)N);
+    const uint64_t halo = tab->max_pat_len > 1 ? (uint64_t)tab->max_pat_len - 1 : 0;
+    for (int k = 0; k < n_chunks; k++) {
+        chunks[k].base = (uint64_t)k * chunk;
+        chunks[k].n_owned = chunks[k].base + chunk <= N ? chunk : N - chunks[k].base;
+        uint64_t end = chunks[k].base + chunks[k].n_owned + halo;
+        if (end > N) end = N;                                    /* walks never read past the scanned bytes */
+        chunks[k].n_avail = end - chunks[k].base;
+    }
+    pthread_mutex_lock(&g_mu);
+    g_blob = blob; g_blob_words = words;
+    g_table_ready = 1;
+    for (int g = 0; g < n_gpu; g++) schedule_reads(&ws[g]);      /* (for the staging buffers that exist already) */
+    pthread_cond_broadcast(&g_cv);
+    pthread_mutex_unlock(&g_mu);
+
+    /* in chunk order: the host formatter prints here; with the device formatter only the frontier moves */
     double emit_ms = 0;
     int emit_failed = 0;
     for (int k = 0; k < n_chunks; k++) {
@@ -332,47 +608,61 @@ int main(int argc, char *argv[]) {
         const int ok = chunks[k].done;
         pthread_mutex_unlock(&g_mu);
         if (!ok) break;
-        double e0 = now_ms();
-        const int64_t wrote = chunks[k].words
-            ? pfac_emit_packed(fpout, chunks[k].words, chunks[k].n_words, chunks[k].word_bytes, chunks[k].tix, chunks[k].n_tiles, chunks[k].base, tab->idmap, emit_threads)
-            : pfac_emit_records_mt(fpout, chunks[k].rec, chunks[k].n_rec, chunks[k].base, tab->idmap, emit_threads);
-        if (wrote < 0) {
-            fprintf(stderr, "write failed\n");
-            emit_failed = 1;
-            pthread_mutex_lock(&g_mu); g_failed = 1; pthread_cond_broadcast(&g_cv); pthread_mutex_unlock(&g_mu);
-            break;
+        if (!emit_device) {
+            double e0 = now_ms();
+            const int64_t wrote = chunks[k].words
+                ? pfac_emit_packed(fpout, chunks[k].words, chunks[k].n_words, chunks[k].word_bytes, chunks[k].tix, chunks[k].n_tiles, chunks[k].base, tab->idmap, emit_threads)
+                : pfac_emit_records_mt(fpout, chunks[k].rec, chunks[k].n_rec, chunks[k].base, tab->idmap, emit_threads);
+            if (wrote < 0) {
+                fprintf(stderr, "write failed\n");
+                emit_failed = 1;
+                set_failed();
+                break;
+            }
+            emit_ms += now_ms() - e0;
+            free(chunks[k].rec); free(chunks[k].words); free(chunks[k].tix);
+            chunks[k].rec = NULL; chunks[k].words = NULL; chunks[k].tix = NULL;
         }
-        emit_ms += now_ms() - e0;
-        total += chunks[k].n_rec;
-        free(chunks[k].rec); free(chunks[k].words); free(chunks[k].tix);
-        chunks[k].rec = NULL; chunks[k].words = NULL; chunks[k].tix = NULL;
         pthread_mutex_lock(&g_mu);
         g_emitted = k + 1;
         pthread_cond_broadcast(&g_cv);
         pthread_mutex_unlock(&g_mu);
     }
     for (int g = 0; g < n_gpu; g++) pthread_join(th[g], NULL);
+    pool_wait_idle(&g_writers);
+    pool_stop(&g_readers);
+    pool_stop(&g_writers);
+    if (g_write_error) { fprintf(stderr, "write failed\n"); emit_failed = 1; }
     fclose(fpout);
-    double t3 = now_ms();
-    double kernel_ms = 0;
+    for (int i = 0; i < g_tbuf_n; i++) pfac_host_free(g_tbuf[i].buf);
+    const double t3 = now_ms();
+    double kernel_ms = 0, text_ms = 0;
+    uint64_t total = 0;
     for (int g = 0; g < n_gpu; g++) {
         if (ws[g].rc) { fprintf(stderr, "%s\n", ws[g].err); return 1; }
         kernel_ms += ws[g].kernel_ms;
+        text_ms += ws[g].text_ms;
+        total += ws[g].matches;
     }
-    if (emit_failed) return 1;
+    if (emit_failed || g_failed) return 1;
     printf("/////////////////////////////////////////////\n");
-    printf("1.Time for  create PFAC + Hashtable : %lf seconds\n", (t1 - t0) / 1e3);
-    printf("2.Time for  %d GPU match progress (%d worker(s); read + H2D + kernel + D2H + emit, %d stream(s) each): %lf mseconds (%.3f GB/s end to end)\n",
+    printf("0.Whole program: %lf mseconds\n", t3 - t_start);
+    printf("1.Time for  create PFAC + Hashtable : %lf seconds (while the GPU contexts were being created)\n", (t1 - t0) / 1e3);
+    printf("2.Time for  %d GPU match progress (%d worker(s); context + read + H2D + kernel + D2H + emit, %d stream(s) each): %lf mseconds (%.3f GB/s end to end)\n",
            n_dev < n_gpu ? n_dev : n_gpu, n_gpu, streamnum, t3 - t2, t3 > t2 ? (double)N / (t3 - t2) / 1e6 : 0.0);
     printf("3.Kernel time summed over chunks: %lf mseconds (%.3f GB/s kernel-resident per GPU)\n", kernel_ms,
            kernel_ms > 0 ? (double)N / kernel_ms / 1e6 : 0.0);
-    printf("4.Time for  emit %llu matches (overlapped with the scan): %lf mseconds\n", (unsigned long long)total, emit_ms);
+    if (emit_device)
+        printf("4.Time for  emit %llu matches (%llu bytes of text formatted on the GPU; D2H + pwrite by %d threads, overlapped with the scan): %lf mseconds\n",
+               (unsigned long long)total, (unsigned long long)g_text_total, emit_threads, text_ms);
+    else
+        printf("4.Time for  emit %llu matches (host formatter on %d threads, overlapped with the scan): %lf mseconds\n", (unsigned long long)total, emit_threads, emit_ms);
     int retries = 0;
     for (int g = 0; g < n_gpu; g++) retries += ws[g].internal_retries;
     if (retries) printf("!! %d scan(s) were repeated after a kernel protocol timeout (PFAC_E_INTERNAL, see stderr): please report\n", retries);
     for (int g = 0; g < n_gpu; g++)
-        printf("5.worker %d (GPU %d) host thread: setup (context, table, pinned staging) %.1f ms, file read %.1f ms (%d threads), waiting for scans/readback %.1f ms\n",
-               g, ws[g].device, ws[g].setup_ms, ws[g].read_ms, read_threads, ws[g].drain_ms);
+        printf("5.worker %d (GPU %d) host thread: setup (context, device buffers, pinned staging) %.1f ms, waiting for the table %.1f ms, for the %d readers %.1f ms, for scans/results %.1f ms\n",
+               g, ws[g].device, ws[g].setup_ms, ws[g].table_wait_ms, read_threads, ws[g].read_wait_ms, ws[g].drain_ms);
     printf("matching process finshed\n");
     printf("/////////////////////////////////////////////\n");
     close(fd);

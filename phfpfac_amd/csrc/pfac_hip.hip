@@ -1849,6 +1849,7 @@ struct Slot {
     unsigned *d_res = nullptr;            // device-side address of h_ctl
     unsigned long long *d_sum = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_h2d = nullptr;          // behind the slot's last pfac_slot_h2d: the host buffer may be reused once it has fired
     uint64_t last_cap = 0, last_tiles = 0, last_total = 0, last_used = 0;
     bool scanned = false, pending = false, last_dense = false;
     unsigned long long *d_dbg = nullptr;  // PFAC_TRACE_BUILD + PFAC_TRACE
@@ -2317,6 +2318,7 @@ int pfac_ctx_create(int device, int n_streams, pfac_ctx **out) {
         HIP_TRY(ctx, hipMalloc((void **)&s.d_sum, 16));
         HIP_TRY(ctx, hipEventCreate(&s.ev0));
         HIP_TRY(ctx, hipEventCreate(&s.ev1));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
     }
     *out = ctx;
     return PFAC_OK;
@@ -2339,6 +2341,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.ev0) (void)hipEventDestroy(s.ev0);
         if (s.ev1) (void)hipEventDestroy(s.ev1);
+        if (s.ev_h2d) (void)hipEventDestroy(s.ev_h2d);
         if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
     }
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
@@ -2420,6 +2423,15 @@ int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, u
     if (!host || dst_offset + n_bytes > s.input_cap) return fail(ctx, PFAC_E_ARG, "pfac_slot_h2d: range exceeds the reserved input buffer");
     USE_DEVICE(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(s.d_input + dst_offset, host, n_bytes, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(ctx, hipEventRecord(s.ev_h2d, s.stream));
+    return PFAC_OK;
+}
+
+int pfac_slot_h2d_wait(pfac_ctx *ctx, int slot) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    USE_DEVICE(ctx);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->slots[slot].ev_h2d));   // (an event never recorded counts as complete)
     return PFAC_OK;
 }
 

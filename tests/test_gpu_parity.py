@@ -76,7 +76,7 @@ def test_gphf_cli_config1(resolve, tmp_path):
     big = tmp_path / "big.txt"
     n = 6 * (1 << 20) + 12345
     big.write_bytes(tiled_bytes(n + 1, para).tobytes())        # + the byte the CLI drops (main.cc:138)
-    env5 = dict(env, PFAC_READ_THREADS="5")                    # every chunk pread() in 5 slices by 5 threads
+    env5 = dict(env, PFAC_READ_THREADS="5", PFAC_EMIT="host")  # a pool of 5 readers; the host formatter
     subprocess.check_call([exe, resolve("xaa"), "3", "1024", str(big)], cwd=tmp_path, env=env5, stdout=subprocess.DEVNULL)
     o = Oracle(resolve("xaa"), 1, 1)
     exp = tmp_path / "expected.txt"
@@ -85,8 +85,8 @@ def test_gphf_cli_config1(resolve, tmp_path):
     assert (tmp_path / "GPU_match_result.txt").read_bytes() == exp.read_bytes()
 
 
-@pytest.mark.parametrize("workers,streams", [(2, 1), (3, 2), (4, 3)])
-def test_gphf_several_workers_share_the_emitter(workers, streams, resolve, tmp_path):
+@pytest.mark.parametrize("workers,streams,emit", [(2, 1, "device"), (3, 2, "host"), (4, 3, "device")])
+def test_gphf_several_workers_share_the_emitter(workers, streams, emit, resolve, tmp_path):
     """The CLI's multi-GPU path (one host thread + context per worker, chunks dealt round-robin over the workers,
     ONE in-order emitter, the bounded window between them -- gphf.c, replacing the OpenMP fan-out of main.cc:180-241)
     with MORE THAN ONE worker: PFAC_WORKERS_PER_GPU runs them on this box's single device.  16 chunks of 1 MiB of the
@@ -98,7 +98,8 @@ def test_gphf_several_workers_share_the_emitter(workers, streams, resolve, tmp_p
     n = 16 * (1 << 20) - 777
     big = tmp_path / "big16.txt"
     big.write_bytes(tiled_bytes(n + 1, para).tobytes())        # + the byte the CLI drops (main.cc:138)
-    env = dict(os.environ, PFAC_CHUNK_MB="1", PFAC_WORKERS_PER_GPU=str(workers), PFAC_READ_THREADS="2", PFAC_EMIT_THREADS="4")
+    env = dict(os.environ, PFAC_CHUNK_MB="1", PFAC_WORKERS_PER_GPU=str(workers), PFAC_READ_THREADS="2", PFAC_EMIT_THREADS="4",
+               PFAC_EMIT=emit)
     out = subprocess.run([exe, resolve("xaa"), str(streams), "256", str(big)], cwd=tmp_path, env=env, capture_output=True,
                          text=True, check=True).stdout
     assert f"({workers} worker(s);" in out
@@ -651,17 +652,20 @@ def test_reference_seam_by_its_own_names(resolve, tmp_path):
         assert name in syms
 
 
-def test_gphf_parallel_emitter_behind_the_scan(resolve, tmp_path):
-    """SURVEY 8(f)1 behind the HIP scan: ONE 64 MiB chunk that yields ~5 M records goes through the multi-threaded
-    emitter (PFAC_EMIT_THREADS=8, well above its 524 288-record threshold), printing straight from the compact
-    device form (record heap + tile index); the file must equal the oracle's text byte for byte."""
+@pytest.mark.parametrize("emit", ["host", "device"])
+def test_gphf_parallel_emitter_behind_the_scan(emit, resolve, tmp_path):
+    """SURVEY 8(f)1 behind the HIP scan: ONE 64 MiB chunk that yields ~5 M records (195 MB of text) goes through (host)
+    the multi-threaded host emitter (PFAC_EMIT_THREADS=8, well above its 524 288-record threshold), printing straight
+    from the compact device form (record heap + tile index), or (device, the default) the GPU-side emitter: text
+    formatted on the device, returned through the ring of 64 MiB pinned buffers and pwrite()n by the writer pool;
+    the file must equal the oracle's text byte for byte."""
     import subprocess
     exe = os.path.join(os.path.dirname(HERE), "phfpfac_amd", "bin", "gphf")
     para = open(resolve("paragraph402"), "rb").read()
     n = (64 << 20) - 4097
     big = tmp_path / "big64.txt"
     big.write_bytes(tiled_bytes(n + 1, para).tobytes())        # + the byte the CLI drops (main.cc:138)
-    env = dict(os.environ, PFAC_EMIT_THREADS="8")
+    env = dict(os.environ, PFAC_EMIT_THREADS="8", PFAC_EMIT=emit, PFAC_CHUNK_MB="64")
     out = subprocess.run([exe, resolve("experimentpattern"), "1", "256", str(big)], cwd=tmp_path, env=env,
                          capture_output=True, text=True, check=True).stdout
     matches = int([l for l in out.splitlines() if l.startswith("4.Time for  emit")][0].split()[3])
@@ -1015,12 +1019,12 @@ def test_gpu_text_emitter_at_size(resolve):
         tail = g.text_to_host(1 << 20, first=nbytes - (1 << 20))
         k = head.count(b"\n")
         rec_head = g.records_to_host(k + 1)
-        rec_tail_n = tail.count(b"\n")
+        rec_tail_n = tail.count(b"\n") - 1                        # (the slice begins inside a line: that one is not compared)
         rec_tail = g.records_to_host(rec_tail_n, first=n - rec_tail_n)
     want_head = "".join("At position %4d, match pattern %d\n" % (p, i) for p, i in zip(rec_head["pos"][:k], table.idmap[rec_head["state"][:k]]))
     assert head.decode().startswith(want_head) and len(want_head) > (1 << 20) - 64
     want_tail = "".join("At position %4d, match pattern %d\n" % (p, i) for p, i in zip(rec_tail["pos"], table.idmap[rec_tail["state"]]))
-    assert tail.decode().endswith(want_tail) and tail.endswith(b"\n")
+    assert tail.decode().endswith(want_tail) and tail.endswith(b"\n") and len(want_tail) > (1 << 20) - 64
     # the total, exactly: the input has period 402, so the match set is {off + 402 q} for the (offset, pattern) pairs of one
     # period, cut where a match would cross N; a line is 12 + max(4, digits(pos)) + 16 + digits(id) + 1 bytes
     win = tiled_bytes(402 * 8, para)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box: end-to-end gphf runs (H2D + scan + D2H + emit) on a generated 1 GiB text file: PCIe-inclusive rate.
+# GPU box: end-to-end gphf runs (read + H2D + scan + text back + write) on a generated text file: the PCIe-inclusive rate.
+#   SIZE=bytes (default 1 GiB)  STREAMS="1 4"  PATS="bytefile_10000byte experimentpattern"  EMIT="device host"
 set -e
 cd "$(dirname "$0")/.."
 D=tests/golden/data
@@ -8,7 +9,7 @@ python3 - "$W" "${SIZE:-1073741824}" <<'PY'
 import sys, os
 para = open("tests/golden/data/paragraph402","rb").read()
 n = int(sys.argv[2])
-with open(os.path.join(sys.argv[1], "text1g"), "wb") as f:
+with open(os.path.join(sys.argv[1], "text"), "wb") as f:
     blk = (para * (1 + (1 << 24) // 402))
     # keep the 402-byte phase continuous across blocks
     off = 0
@@ -19,16 +20,18 @@ with open(os.path.join(sys.argv[1], "text1g"), "wb") as f:
         off += k
     f.write(b"\n")
 PY
+for e in ${EMIT:-device}; do
 for s in ${STREAMS:-1 4}; do
   for p in ${PATS:-bytefile_10000byte experimentpattern}; do
     (
       cd $W
       T0=$(date +%s.%N)
-      $OLDPWD/phfpfac_amd/bin/gphf $OLDPWD/$D/$p $s 256 $W/text1g | grep -E "^2\.|^3\.|^4\.|^5\."
+      PFAC_EMIT=$e $OLDPWD/phfpfac_amd/bin/gphf $OLDPWD/$D/$p $s 256 $W/text | grep -E "^0\.|^2\.|^3\.|^4\.|^5\.|^!!"
       T1=$(date +%s.%N)
-      python3 -c "print('wall %.2f s (whole program incl. table build, file read, emit)' % ($T1 - $T0))"
+      python3 -c "print('wall %.2f s (whole process incl. exec, table build, file read, emit)' % ($T1 - $T0))"
       ls -la GPU_match_result.txt | awk '{print "output bytes", $5}'
-    ) 2>&1 | sed "s/^/[$p streams=$s] /"
+    ) 2>&1 | sed "s/^/[$p streams=$s emit=$e] /"
   done
+done
 done
 rm -rf $W
