@@ -225,6 +225,8 @@ int pfac_slot_h2d(pfac_ctx *ctx, int slot, const void *host, uint64_t n_bytes, u
 /* Block until the slot's last pfac_slot_h2d has left the host buffer (which may then be refilled while the scan that
  * follows it on the stream is still running): what lets a reader pool run ahead of the copies. */
 int pfac_slot_h2d_wait(pfac_ctx *ctx, int slot);
+/* The same question without blocking: 1 = it has, 0 = not yet, negative = error. */
+int pfac_slot_h2d_done(pfac_ctx *ctx, int slot);
 
 /*
  * The scan: replaces the kernel launch of GPU_TraceTable (master_kernel.cu:396-423).

@@ -83,7 +83,7 @@ HIP_SYMBOLS = (
     "pfac_scan_finish", "pfac_scan_elapsed_ms", "pfac_records_d2h", "pfac_slot_sync", "pfac_records_checksum",
     "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_scan_staging", "pfac_trace_table_compat", "pfac_scan_format",
     "pfac_records_expand", "pfac_records_d2h_packed", "pfac_scan_capacity_hint", "pfac_records_packed_device",
-    "pfac_emit_text_device", "pfac_text_d2h", "pfac_slot_text", "pfac_slot_h2d_wait",
+    "pfac_emit_text_device", "pfac_text_d2h", "pfac_slot_text", "pfac_slot_h2d_wait", "pfac_slot_h2d_done",
 )
 
 _host = None
@@ -173,6 +173,7 @@ def hip_lib() -> C.CDLL:
         L.pfac_slot_set_stream.argtypes = [vp, i, vp]
         L.pfac_slot_h2d.argtypes = [vp, i, vp, u64, u64]
         L.pfac_slot_h2d_wait.argtypes = [vp, i]
+        L.pfac_slot_h2d_done.argtypes = [vp, i]
         L.pfac_scan_async.argtypes = [vp, i, vp, u64, u64, vp, u64]
         L.pfac_scan_finish.argtypes = [vp, i, C.POINTER(u64)]
         L.pfac_scan_elapsed_ms.argtypes = [vp, i, C.POINTER(C.c_float)]

@@ -115,6 +115,12 @@ static double now_ms(void) {
     return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
 
+/* PFAC_TIMELINE=1: milestones on stderr, milliseconds since program start */
+static double g_t_start = 0;
+static int g_timeline = 0;
+static int g_skip_read = 0, g_skip_gpu = 0;     /* diagnostics (PFAC_GPHF_SKIP=read|gpu): time one half of the pipeline alone; results are wrong */
+#define MILESTONE(...) do { if (g_timeline) { fprintf(stderr, "[%9.2f ms] ", now_ms() - g_t_start); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
+
 static void set_failed(void) {
     pthread_mutex_lock(&g_mu);
     g_failed = 1;
@@ -224,7 +230,7 @@ static void read_piece(void *a, uint64_t stage_idx, uint64_t chunk_ord, uint64_t
     stage_t *st = &w->stage[stage_idx];
     const chunk_t *c = &w->chunks[w->index + (int)chunk_ord * w->n_workers];
     const uint64_t n = c->n_avail - off < w->piece ? c->n_avail - off : w->piece;
-    const int rc = read_fully(w->fd, (unsigned char *)st->buf + off, n, c->base + off);
+    const int rc = g_skip_read ? 0 : read_fully(w->fd, (unsigned char *)st->buf + off, n, c->base + off);
     pthread_mutex_lock(&g_mu);
     if (rc) st->io_error = 1;
     if (--st->pieces_left == 0) {
@@ -345,6 +351,7 @@ static int drain(worker_t *w, pfac_ctx *ctx, int slot, int k, uint64_t *cap) {
         const double t0 = now_ms();
         uint64_t tb = 0;
         if (n && (rc = pfac_emit_text_device(ctx, slot, NULL, c->base, &tb))) return fail(w, ctx, rc, "device text emitter");
+        if (k < 2) MILESTONE("worker %d: chunk %d: %llu bytes of text formatted on the device", w->index, k, (unsigned long long)tb);
         /* file offsets go out in chunk order: this chunk's is known once every earlier chunk has reported its size */
         pthread_mutex_lock(&g_mu);
         c->text_bytes = tb;
@@ -404,6 +411,7 @@ static void *worker(void *arg) {
     pfac_ctx *ctx = NULL;
     uint64_t *cap = NULL;
     int *busy = NULL;               /* chunk index occupying each slot, or -1 */
+    int freed = 0;                  /* this worker's chunks [0, freed) have given their staging buffers back */
     const double ts = now_ms();
     int rc = pfac_ctx_create(w->device, w->n_streams, &ctx);
     if (rc) {
@@ -432,6 +440,7 @@ static void *worker(void *arg) {
             }
     }
     w->setup_ms = now_ms() - ts;
+    MILESTONE("worker %d: context, device buffers, %d pinned staging buffers ready", w->index, w->n_stage);
     {
         const double tw = now_ms();
         pthread_mutex_lock(&g_mu);
@@ -442,6 +451,7 @@ static void *worker(void *arg) {
         w->table_wait_ms = now_ms() - tw;
     }
     if ((rc = pfac_table_upload(ctx, g_blob, g_blob_words))) { fail(w, ctx, rc, "table upload"); goto out; }
+    MILESTONE("worker %d: table installed", w->index);
     for (int j = 0; j < w->n_mine && !w->rc; j++) {
         const int k = w->index + j * w->n_workers;
         const int slot = j % w->n_streams;
@@ -450,30 +460,57 @@ static void *worker(void *arg) {
         if (busy[slot] >= 0 && drain(w, ctx, slot, busy[slot], &cap[slot])) break;
         w->drain_ms += now_ms() - td;
         busy[slot] = -1;
-        /* bounded memory: do not run further ahead of the in-order output than the window; then wait for the readers */
+        /* bounded memory: do not run further ahead of the in-order output than the window; then wait for the readers.
+         * Staging buffers go back to the readers as soon as their copies have left them (asked without blocking, oldest
+         * first), so the reads run ahead and several copies are always queued; the worker blocks on a copy only when the
+         * buffer it needs next still holds an older chunk. */
         const double tr = now_ms();
+        stage_t *st = &w->stage[j % w->n_stage];
+        int stop = 0, ioerr = 0;
         pthread_mutex_lock(&g_mu);
         while (k >= g_emitted + g_window && !g_failed) pthread_cond_wait(&g_cv, &g_mu);
-        stage_t *st = &w->stage[j % w->n_stage];
-        while (st->state != ST_READY && !g_failed) pthread_cond_wait(&g_cv, &g_mu);
-        const int stop = g_failed, ioerr = st->io_error;
-        if (!stop) st->state = ST_INFLIGHT;
+        for (;;) {
+            int block = st->state == ST_INFLIGHT;       /* (only ever true for the oldest unreleased chunk's buffer) */
+            while (freed < j) {
+                pthread_mutex_unlock(&g_mu);
+                const int sl = freed % w->n_streams;
+                const int done = block ? (pfac_slot_h2d_wait(ctx, sl) ? -1 : 1) : pfac_slot_h2d_done(ctx, sl);
+                pthread_mutex_lock(&g_mu);
+                if (done < 0) { rc = done; break; }
+                if (!done) break;
+                w->stage[freed % w->n_stage].state = ST_FREE;
+                freed++;
+                schedule_reads(w);
+                block = 0;
+            }
+            if (rc < 0 || g_failed || st->state == ST_READY) break;
+            if (st->state == ST_INFLIGHT) continue;     /* its copy was still running: wait for it (block) */
+            struct timespec until;
+            clock_gettime(CLOCK_REALTIME, &until);
+            until.tv_nsec += 200000;                    /* the readers are at it: look again at the copies in 0.2 ms at the latest */
+            if (until.tv_nsec >= 1000000000) { until.tv_nsec -= 1000000000; until.tv_sec++; }
+            pthread_cond_timedwait(&g_cv, &g_mu, &until);
+        }
+        stop = g_failed;
+        ioerr = st->io_error;
+        if (!stop && rc >= 0) st->state = ST_INFLIGHT;
         pthread_mutex_unlock(&g_mu);
         w->read_wait_ms += now_ms() - tr;
+        if (rc < 0) { fail(w, ctx, rc, "h2d wait"); break; }
         if (stop) break;
         if (ioerr) { fail(w, NULL, PFAC_E_IO, "short read on the input file"); break; }
+        if (g_skip_gpu) {                           /* diagnostic: the reader pool alone */
+            pthread_mutex_lock(&g_mu);
+            st->state = ST_FREE;
+            freed = j + 1;
+            schedule_reads(w);
+            pthread_mutex_unlock(&g_mu);
+            chunk_done(c);
+            continue;
+        }
         if (c->n_avail && (rc = pfac_slot_h2d(ctx, slot, st->buf, c->n_avail, 0))) { fail(w, ctx, rc, "h2d"); break; }
         if ((rc = pfac_scan_async(ctx, slot, NULL, c->n_owned, c->n_avail, NULL, 0))) { fail(w, ctx, rc, "scan"); break; }
         busy[slot] = k;
-        /* the PREVIOUS chunk's copy has had a whole iteration: once it has left its staging buffer the readers get that
-         * buffer back (with one slot this waits for the copy just issued, which is behind it on the same stream) */
-        if (j > 0) {
-            if ((rc = pfac_slot_h2d_wait(ctx, (j - 1) % w->n_streams))) { fail(w, ctx, rc, "h2d wait"); break; }
-            pthread_mutex_lock(&g_mu);
-            w->stage[(j - 1) % w->n_stage].state = ST_FREE;
-            schedule_reads(w);
-            pthread_mutex_unlock(&g_mu);
-        }
     }
     for (int s = 0; s < w->n_streams && !w->rc; s++) {      /* drain what is still in flight, oldest first */
         int lowest = -1;
@@ -484,6 +521,7 @@ static void *worker(void *arg) {
         busy[lowest] = -1;
     }
 out:
+    MILESTONE("worker %d: last chunk drained", w->index);
     if (w->rc) set_failed();
     pool_wait_idle(&g_readers);     /* no reader may still write into the staging buffers freed below */
     for (int b = 0; b < w->n_stage; b++) pfac_host_free(w->stage[b].buf);
@@ -498,6 +536,9 @@ int main(int argc, char *argv[]) {
         exit(-1);
     }
     const double t_start = now_ms();
+    g_t_start = t_start;
+    g_timeline = getenv("PFAC_TIMELINE") != NULL;
+    if (getenv("PFAC_GPHF_SKIP")) { g_skip_read = strcmp(getenv("PFAC_GPHF_SKIP"), "read") == 0; g_skip_gpu = strcmp(getenv("PFAC_GPHF_SKIP"), "gpu") == 0; }
     int streamnum = atoi(argv[2]);
     int width = atoi(argv[3]);
     if (streamnum < 1) { fprintf(stderr, "streamnum must be >= 1\n"); return 1; }
@@ -508,7 +549,9 @@ int main(int argc, char *argv[]) {
     uint64_t N = st.st_size > 0 ? (uint64_t)st.st_size - 1 : 0;  /* the last byte is dropped, main.cc:138 */
 
     int rc, n_gpu = 0;
+    MILESTONE("input opened");
     if ((rc = pfac_device_count(&n_gpu)) || n_gpu < 1) { fprintf(stderr, "no GPU available: %s\n", pfac_last_error(NULL)); return 1; }
+    MILESTONE("HIP runtime up, %d device(s)", n_gpu);
     const char *lim = getenv("PFAC_GPUS");
     if (lim && atoi(lim) > 0 && atoi(lim) < n_gpu) n_gpu = atoi(lim);
     const int n_dev = n_gpu;
@@ -595,6 +638,7 @@ int main(int argc, char *argv[]) {
     pthread_mutex_lock(&g_mu);
     g_blob = blob; g_blob_words = words;
     g_table_ready = 1;
+    MILESTONE("table built (%.1f ms), chunk plan published", t1 - t0);
     for (int g = 0; g < n_gpu; g++) schedule_reads(&ws[g]);      /* (for the staging buffers that exist already) */
     pthread_cond_broadcast(&g_cv);
     pthread_mutex_unlock(&g_mu);
@@ -628,14 +672,19 @@ int main(int argc, char *argv[]) {
         pthread_cond_broadcast(&g_cv);
         pthread_mutex_unlock(&g_mu);
     }
+    MILESTONE("every chunk's results handed over");
     for (int g = 0; g < n_gpu; g++) pthread_join(th[g], NULL);
+    MILESTONE("workers joined (contexts destroyed, staging unpinned)");
     pool_wait_idle(&g_writers);
+    MILESTONE("writers idle");
     pool_stop(&g_readers);
     pool_stop(&g_writers);
     if (g_write_error) { fprintf(stderr, "write failed\n"); emit_failed = 1; }
     fclose(fpout);
+    MILESTONE("output closed");
     for (int i = 0; i < g_tbuf_n; i++) pfac_host_free(g_tbuf[i].buf);
     const double t3 = now_ms();
+    MILESTONE("text buffers unpinned");
     double kernel_ms = 0, text_ms = 0;
     uint64_t total = 0;
     for (int g = 0; g < n_gpu; g++) {

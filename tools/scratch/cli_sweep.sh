@@ -1,0 +1,26 @@
+set -e
+cd /root/repo
+D=tests/golden/data
+W=$(mktemp -d)
+python3 - "$W" "17179869184" <<'PY'
+import sys, os
+para = open("tests/golden/data/paragraph402","rb").read()
+n = int(sys.argv[2])
+with open(os.path.join(sys.argv[1], "text"), "wb") as f:
+    blk = (para * (1 + (1 << 24) // 402))
+    off = 0
+    while off < n:
+        k = min(1 << 24, n - off)
+        ph = off % 402
+        f.write((para[ph:] + blk)[:k])
+        off += k
+    f.write(b"\n")
+PY
+cd $W
+run() { echo "== S=$S $*"; env "$@" /root/repo/phfpfac_amd/bin/gphf /root/repo/$D/bytefile_10000byte $S 256 $W/text | grep -E "^2\.|^5\." | sed 's/(1 worker.*each)//'; }
+for S in 1 2 4; do run PFAC_GPHF_SKIP=read; done
+for S in 1 2 4; do run PFAC_READ_THREADS=12; done
+S=4; run PFAC_READ_THREADS=14
+S=4; run PFAC_READ_THREADS=12 PFAC_CHUNK_MB=64
+S=3; run PFAC_READ_THREADS=12
+rm -rf $W
