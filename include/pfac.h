@@ -208,6 +208,11 @@ int pfac_table_upload_device(pfac_ctx *ctx, const void *d_blob, size_t n_words, 
 /* Pinned host memory, replaces cudaHostAlloc(..., cudaHostAllocPortable) (main.cc:147,161). */
 int pfac_host_alloc(void **p, size_t n_bytes);
 void pfac_host_free(void *p);
+/* Make an existing, page-aligned host range DMA-able in place -- e.g. a MAP_SHARED mapping of the input file: the H2D
+ * copy then reads the page cache itself, and no CPU thread copies the input at all (gphf's default ingest).  Ranges
+ * must not overlap; unregister before unmapping.  Fails (PFAC_E_HIP) where the driver cannot pin the pages. */
+int pfac_host_register(void *p, size_t n_bytes);
+int pfac_host_unregister(void *p);
 
 /* Per-slot device buffers owned by the context.  Input capacity is rounded up
  * so the kernel's tile loads stay in bounds (master_kernel.cu:217 pads by

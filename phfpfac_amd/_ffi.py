@@ -83,7 +83,7 @@ HIP_SYMBOLS = (
     "pfac_scan_finish", "pfac_scan_elapsed_ms", "pfac_records_d2h", "pfac_slot_sync", "pfac_records_checksum",
     "pfac_fill_tiled", "pfac_fill_random", "pfac_scan_info", "pfac_scan_staging", "pfac_trace_table_compat", "pfac_scan_format",
     "pfac_records_expand", "pfac_records_d2h_packed", "pfac_scan_capacity_hint", "pfac_records_packed_device",
-    "pfac_emit_text_device", "pfac_text_d2h", "pfac_slot_text", "pfac_slot_h2d_wait", "pfac_slot_h2d_done",
+    "pfac_emit_text_device", "pfac_text_d2h", "pfac_slot_text", "pfac_slot_h2d_wait", "pfac_slot_h2d_done", "pfac_host_register", "pfac_host_unregister",
 )
 
 _host = None
@@ -161,6 +161,8 @@ def hip_lib() -> C.CDLL:
         L.pfac_table_upload.argtypes = [vp, vp, C.c_size_t]
         L.pfac_table_upload_device.argtypes = [vp, vp, C.c_size_t, vp]
         L.pfac_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+        L.pfac_host_register.argtypes = [vp, C.c_size_t]
+        L.pfac_host_unregister.argtypes = [vp]
         L.pfac_host_free.argtypes = [vp]
         L.pfac_host_free.restype = None
         L.pfac_slot_reserve.argtypes = [vp, i, u64, u64]

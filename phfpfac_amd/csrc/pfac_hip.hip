@@ -2390,6 +2390,19 @@ int pfac_host_alloc(void **p, size_t n_bytes) {
 }
 void pfac_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+int pfac_host_register(void *p, size_t n_bytes) {
+    if (!p || !n_bytes) return fail(nullptr, PFAC_E_ARG, "bad argument to pfac_host_register");
+    hipError_t e = hipHostRegister(p, n_bytes, hipHostRegisterPortable);     // (usable from every device's context)
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, PFAC_E_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    return PFAC_OK;
+}
+int pfac_host_unregister(void *p) {
+    if (!p) return fail(nullptr, PFAC_E_ARG, "null argument");
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, PFAC_E_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
+    return PFAC_OK;
+}
+
 int pfac_slot_reserve(pfac_ctx *ctx, int slot, uint64_t input_bytes, uint64_t record_capacity) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
