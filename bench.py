@@ -44,7 +44,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 DATA = os.path.join(REPO, "tests", "golden", "data")
 KERNEL_SRC = os.path.join(REPO, "phfpfac_amd", "csrc", "pfac_hip.hip")
-PROFILE = os.path.join(REPO, "profiles", "r2_pmc_per_launch.json")
+PROFILE = os.path.join(REPO, "profiles", "r3_pmc_per_launch.json")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GIB = 1 << 30
 
@@ -243,8 +243,8 @@ def committed_traffic():
         prof = json.load(open(PROFILE))
         src = hashlib.sha256(open(KERNEL_SRC, "rb").read()).hexdigest()
         if prof.get("kernel_source_sha256") == src:
-            return prof.get("derived_hbm_bytes"), "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, profiles/r2_pmc_per_launch.json (same kernel source)"
-        return None, "profiles/r2_pmc_per_launch.json was taken from a different kernel source: not reported"
+            return prof.get("derived_hbm_bytes"), "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, profiles/r3_pmc_per_launch.json (same kernel source)"
+        return None, "profiles/r3_pmc_per_launch.json was taken from a different kernel source: not reported"
     except (OSError, ValueError):
         return None, "no committed PMC profile"
 
@@ -483,6 +483,15 @@ def main():
                 res["readback_ms"] = (time.perf_counter() - t1) * 1e3
             res["readback_bytes"] = used * rec_b + n_tiles * 8
             del words_h, tix_h
+            if world == 1:
+                # the GPU-side text emitter (main.cc:335-350 on the device): the same records -> finished lines of
+                # GPU_match_result.txt in a device buffer (size pass, prefix sum, format); twice: the first call allocates
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    res["emit_text_bytes"] = g.emit_text_device(lo, slot=1)
+                    g.sync(1)
+                    res["emit_text_ms"] = (time.perf_counter() - t1) * 1e3
             if use_dist:
                 dist.barrier()
                 torch.cuda.synchronize()
@@ -527,6 +536,9 @@ def main():
                    "expand_ms": round(res["expand_ms"], 3),
                    "expand_note": "heap -> one sorted pfac_record array on the device, outside the timed region (what an ordered consumer pays)",
                    "readback_ms": round(res["readback_ms"], 3), "readback_bytes": res["readback_bytes"],
+                   **({"emit_text_ms": round(res["emit_text_ms"], 3), "emit_text_bytes": res["emit_text_bytes"],
+                       "emit_text_note": "GPU-side text emitter (pfac_emit_text_device): these records formatted into the lines of GPU_match_result.txt in device memory, outside the timed region"}
+                      if "emit_text_ms" in res else {}),
                    "readback_note": "D2H of the compact form (record heap + tile index) into pinned host memory, outside the timed region (the reference's dense D2H, master_kernel.cu:428, made compact)",
                    "multi_gpu_note": "N > 1 numbers exist only where the driver ran them (SCALE_rNN.json): the builder's box has one GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -10,7 +10,7 @@ for pass in "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_CYCLES SQ_BUSY_CU_CYCL
             "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU" \
             "SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL"; do
   i=$((i+1))
-  rocprofv3 --pmc $pass --output-format csv -d $out/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > $out/p$i.log 2>&1 || echo "pass failed: $pass" >> $out/errors.log
+  rocprofv3 --pmc $pass --output-format csv -d $out/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-end-to-end --sustain-seconds 0 "$@" > $out/p$i.log 2>&1 || echo "pass failed: $pass" >> $out/errors.log
 done
 python3 - $out <<'PY'
 import sys, glob, csv, collections

@@ -9,7 +9,7 @@ for pass in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_
             "SQC_ICACHE_BUSY_CYCLES SQC_ICACHE_INPUT_VALID_READYB SQC_TC_INST_REQ SQC_TC_STALL" \
             "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_BUSY_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $pass --output-format csv -d $out/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > $out/p$i.log 2>&1 || echo "pass failed: $pass" >> $out/errors.log
+  rocprofv3 --pmc $pass --output-format csv -d $out/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-end-to-end --sustain-seconds 0 "$@" > $out/p$i.log 2>&1 || echo "pass failed: $pass" >> $out/errors.log
 done
 python3 - $out <<'PY'
 import sys, glob, csv, collections
