@@ -360,6 +360,9 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
     unsigned win[NWALK], left[NWALK], f[NWALK];                // left: bytes the walk may still read after its first
     int s[NWALK], rn[NWALK];                                   // rn: r[row of s] (FUSED)
+    // (not with four walks per lane, the dense-match regime: there the tests cost more issue slots than the gathers they save
+    // cost time -- the dictionary on text measured 3.5 % slower with them)
+    constexpr bool USE_CM = FUSED && NWALK < 4;
     unsigned cm[NWALK];                                        // FUSED: child mask of s -- bit (b & 31) set iff s has an edge on some byte
                                                                // congruent to b mod 32 (all ones where it is not known): a walker whose next
                                                                // byte's bit is clear is dead WITHOUT the L2 round trip that would say so
@@ -402,7 +405,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             m[w][0] = fin ? (unsigned)s[w] : m[w][0];
             n[w] += fin ? 1u : 0u;
             go[w] = s[w] >= 0 && k < left[w];
-            if (FUSED && masked) go[w] = go[w] && ((cm[w] >> ((win[w] >> (8 * bi)) & 31u)) & 1u) != 0u;
+            if (USE_CM && masked) go[w] = go[w] && ((cm[w] >> ((win[w] >> (8 * bi)) & 31u)) & 1u) != 0u;
             any = any || go[w];
         }
         return __any(any);
@@ -532,7 +535,7 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
             const unsigned lo = t32[p >> 2], hi = t32[(p >> 2) + 1];
             win[w] = __builtin_amdgcn_alignbyte(hi, lo, p & 3u);
         }
-        if (FUSED) {                                           // the child masks against the first byte of the new windows
+        if (USE_CM) {                                          // the child masks against the first byte of the new windows
             bool any = false;
 #pragma unroll
             for (int w = 0; w < NWALK; w++) {
