@@ -797,8 +797,15 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
                 TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, head, RW, lane, stage, lim, tile_base, wrun)));
         }
     }
-    // (the last, partial round runs where its entries lie: nothing is appended behind them any more)
-    if (tail > head) TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, head, tail - head, lane, stage, lim, tile_base, wrun)));
+    // (the last, partial round runs where its entries lie: nothing is appended behind them any more; with two walks per
+    // lane and at most 64 entries left, the one-walk form of the round does the same work in half the instructions -- the
+    // sparse L2-table kernels are paced by their instruction stream, and their typical tile ends on such a round)
+    if (tail > head) {
+        if (NWALK == 2 && !DIRECT && tail - head <= (unsigned)WAVE)
+            TP_ROUND((wrun += roundN<W8, DIRECT, 1, FUSED, ROOT>(a, tile, s0, d1, R, T, q, head, tail - head, lane, stage, lim, tile_base, wrun)));
+        else
+            TP_ROUND((wrun += roundN<W8, DIRECT, NWALK, FUSED, ROOT>(a, tile, s0, d1, R, T, q, head, tail - head, lane, stage, lim, tile_base, wrun)));
+    }
 #ifdef PFAC_TRACE_BUILD
     if (!DIRECT && a.dbg && blockIdx.x < 8 && lane == 0 && (threadIdx.x >> 6) == 0) {
         // compute wave 0 of the first 8 workgroups: accumulated over the launch (slot 31 of the block's first row)
