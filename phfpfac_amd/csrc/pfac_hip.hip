@@ -1990,8 +1990,15 @@ int ensure_tiles(pfac_ctx *ctx, Slot &s, uint64_t n_entries) {
     return PFAC_OK;
 }
 
+// Tuning and test knobs (PFAC_FORCE_L2, PFAC_NWB, PFAC_FAULT, ...) are honoured ONLY in a process that opts in with
+// PFAC_ENABLE_KNOBS=1 (the tests and the tools do): a production process cannot have its scans altered -- or a fault injected
+// -- by a stray environment variable.
+const char *knob(const char *name) {
+    static const bool enabled = [] { const char *v = getenv("PFAC_ENABLE_KNOBS"); return v && *v && *v != '0'; }();
+    return enabled ? getenv(name) : nullptr;
+}
 int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
+    const char *v = knob(name);
     return v && *v ? atoi(v) : dflt;
 }
 
@@ -2010,7 +2017,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     // table bytes if staged in LDS: r (16-B rounded) + T
     const size_t tbytes = align_up((size_t)ctx->max_row * 4, 16) + (size_t)ctx->ht_size * 8;
     ctx->variant = tbytes <= (size_t)LDS_TABLE_MAX ? 0 : 1;
-    if (getenv("PFAC_FORCE_L2")) ctx->variant = 1;             // tuning knob: tables via L2 even if they fit LDS
+    if (knob("PFAC_FORCE_L2")) ctx->variant = 1;             // tuning knob: tables via L2 even if they fit LDS
     int halo = ctx->max_pat_len > 1 ? ctx->max_pat_len - 1 : 0;
     ctx->halo = (halo + 15) & ~15;
     // dense rows for the depth-1 states (children of the root), when there are few enough of them
@@ -2022,10 +2029,10 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         if (s0_host[i] >= 0) { d1state[fan] = s0_host[i]; d1idx[i] = (unsigned char)(fan < 255 ? fan : 255); fan++; rb = i; }
     }
     // (rows are built in device memory in full, 256 columns; LDS takes the columns that have an edge in some row)
-    ctx->d1_rows = (fan >= 1 && fan <= 255 && !getenv("PFAC_NO_D1")) ? fan : 0;
+    ctx->d1_rows = (fan >= 1 && fan <= 255 && !knob("PFAC_NO_D1")) ? fan : 0;
     ctx->d1_stride = 0; ctx->d1_lds_bytes = 0;
     // tables via L2 and PHF width >= 256: fused slots, one gather per step
-    const bool fused = ctx->variant == 1 && ctx->width_bit >= 8 && !getenv("PFAC_NO_FUSE");
+    const bool fused = ctx->variant == 1 && ctx->width_bit >= 8 && !knob("PFAC_NO_FUSE");
     ctx->d1_n2 = 0;
     if (ctx->d_d1) { HIP_TRY(ctx, hipFree(ctx->d_d1)); ctx->d_d1 = nullptr; }
     if (ctx->d1_rows) {
@@ -2065,7 +2072,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
             HIP_TRY(ctx, hipMemcpy(b + off_col, colmap, 256, hipMemcpyHostToDevice));
             HIP_TRY(ctx, hipMemcpy(b + off_col + 256, colbyte, 256, hipMemcpyHostToDevice));
         }
-        if (ctx->d1_rows && fused && ctx->state_num <= (1 << D1_STATE_BITS) && !getenv("PFAC_NO_D1PACK")) {
+        if (ctx->d1_rows && fused && ctx->state_num <= (1 << D1_STATE_BITS) && !knob("PFAC_NO_D1PACK")) {
             // how many depth-2 states are there?
             int n2 = 0;
             for (int v : rows) n2 += v >= 0;
@@ -2104,7 +2111,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     HIP_TRY(ctx, hipMemcpy(ctx->d_bm2 + 256 * 32, bm2_host.data() + 256 * 32, 256, hipMemcpyHostToDevice));
     bool any_fin1 = false;                                  // a 1-byte pattern: its survivors are kept whatever follows
     for (int i = 0; i < 256; i++) any_fin1 = any_fin1 || (s0_host[i] >= 0 && s0_host[i] < ctx->num_final);
-    ctx->sec_filter = (fan != 1 && !any_fin1 && !getenv("PFAC_NO_SECF")) ? 1 : 0;
+    ctx->sec_filter = (fan != 1 && !any_fin1 && !knob("PFAC_NO_SECF")) ? 1 : 0;
     if (fan == 1) {
         const unsigned char *row = bm2_host.data() + (size_t)rb * 32;
         int nch = 0, ch[2] = {0, 0};
@@ -2138,7 +2145,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     if (ctx->spin_max < 64) ctx->spin_max = 64;
     ctx->fault = (unsigned)env_int("PFAC_FAULT", 0);
     ctx->ticket_ways_knob = (unsigned)env_int("PFAC_TICKET_WAYS", 0);
-    ctx->trace_file = getenv("PFAC_TRACE") ? getenv("PFAC_TRACE") : "";
+    ctx->trace_file = knob("PFAC_TRACE") ? knob("PFAC_TRACE") : "";
     // The two-buffer layout fixes the number of waves; LDS that no further wave fits into goes to the staging buffers
     // (up to 1024 records per 4 KiB tile before it has to be walked a second time).  The three-buffer layout (emission
     // at the top of the round, see NBUF_MAX) is used when it keeps that many waves with room for >= CAPW3_MIN records.
@@ -2178,7 +2185,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->root_state = s0_host[rb];
     // records are as wide as the automaton needs: 12 position bits + the final state
     ctx->rec_bytes = ctx->num_final <= 16 ? 2 : (ctx->num_final <= (1 << PACK_STATE_BITS) ? 4 : 8);
-    const int rb_knob = env_int("PFAC_REC_BYTES", getenv("PFAC_WIDE") ? 8 : 0);     // test knob: a WIDER form than needed
+    const int rb_knob = env_int("PFAC_REC_BYTES", knob("PFAC_WIDE") ? 8 : 0);     // test knob: a WIDER form than needed
     if ((rb_knob == 4 || rb_knob == 8) && rb_knob > ctx->rec_bytes) ctx->rec_bytes = rb_knob;
     if (ctx->rec_bytes == 8) {                              // nothing is staged: every tile is written as it is walked
         ctx->lay[0].stage_cap = ctx->lay[1].stage_cap = 0u;
@@ -2192,7 +2199,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     ctx->lds_bytes_d = ctx->shared_bytes + (nwd - 1) * ctx->pw_bytes_d;
     if (ctx->lds_bytes_d < LDS_TOTAL / 2 + 256) ctx->lds_bytes_d = LDS_TOTAL / 2 + 256;
     ctx->stage_cap_d = (nwd >= 4 && ctx->lay[0].stage_cap) ? (unsigned)CAPW_DENSE : 0u;   // 0: dense mode unavailable
-    ctx->dense_forced = getenv("PFAC_DENSE") ? atoi(getenv("PFAC_DENSE")) : -1;
+    ctx->dense_forced = knob("PFAC_DENSE") ? atoi(knob("PFAC_DENSE")) : -1;
     ctx->dense = ctx->dense_forced == 1 && ctx->stage_cap_d;
     const bool w8 = ctx->width_bit == 8;
     if (ctx->d_T4_alloc) { HIP_TRY(ctx, hipFree(ctx->d_T4_alloc)); ctx->d_T4_alloc = ctx->d_T4 = nullptr; }
@@ -2240,7 +2247,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         ctx->kernel3 = k3[ctx->variant == 0 ? 1 : (fused ? 2 : 0)][w8 ? 1 : 0][ctx->root_mode];
         HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel3, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
     }
-    if (fused && !getenv("PFAC_NO_NW4")) {
+    if (fused && !knob("PFAC_NO_NW4")) {
         ctx->kernel_d = k[3][w8 ? 1 : 0][ctx->root_mode];
         if (ctx->waves_per_block_d > MAX_WAVES_NW4) {
             ctx->waves_per_block_d = MAX_WAVES_NW4;

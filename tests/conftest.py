@@ -14,6 +14,8 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 DATA = os.path.join(HERE, "golden", "data")
+# the kernel's tuning / test knobs (PFAC_FORCE_L2, PFAC_FAULT, ...) are honoured only by a process that opts in
+os.environ.setdefault("PFAC_ENABLE_KNOBS", "1")
 
 
 def pytest_configure(config):

@@ -1042,3 +1042,18 @@ def test_gpu_text_emitter_at_size(resolve):
             lines += c
             total += c * (12 + d + 16 + len(str(int(pid))) + 1)
     assert lines == n and total == nbytes
+
+
+def test_knobs_are_opt_in(resolve):
+    """A production process cannot have its scans altered by a stray environment variable: the kernel's tuning and test
+    knobs are read only when PFAC_ENABLE_KNOBS=1 (this test suite sets it in conftest.py).  Without it PFAC_FORCE_L2 and
+    PFAC_FAULT are ignored; with it they act."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from phfpfac_amd import GpuMatcher, PfacTable\n"
+            "g = GpuMatcher(0, 1); g.load_table(PfacTable.from_file(%r, 256)); print(g.info()['variant'])"
+            % (os.path.dirname(HERE), resolve("experimentpattern")))
+    base = {k: v for k, v in os.environ.items() if not k.startswith("PFAC_")}
+    off = subprocess.run([sys.executable, "-c", code], env=dict(base, PFAC_FORCE_L2="1", PFAC_FAULT="1"), capture_output=True, text=True, check=True)
+    on = subprocess.run([sys.executable, "-c", code], env=dict(base, PFAC_FORCE_L2="1", PFAC_ENABLE_KNOBS="1"), capture_output=True, text=True, check=True)
+    assert off.stdout.split()[-1] == "tables_in_lds" and on.stdout.split()[-1] == "tables_via_l2"

@@ -23,6 +23,7 @@ declare -A ABL=(
   [static]="-DPFAC_ABL_STATIC"       # batches dealt round-robin instead of by ticket
 )
 set -e
+export PFAC_ENABLE_KNOBS=1
 cd "$(dirname "$0")/.."
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude"
 case "$1" in

@@ -1,6 +1,7 @@
 """GPU differential fuzz: random pattern sets x random inputs, random kernel knobs, every record compared with the CPU oracle.
 usage: fuzz.py [seconds] [seed]"""
 import os, sys, tempfile, time
+os.environ.setdefault("PFAC_ENABLE_KNOBS", "1")     # tuning / test knobs of libpfac_hip.so are opt-in
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,6 +1,7 @@
 """GPU diagnostic: kernel time of one scan workload against the shard size -> the fixed cost of a launch (prologue,
 first tiles, tail, exit protocol) and the marginal rate.  usage: size_sweep.py [pattern fixture]   (PFAC_HIP_LIB selects the build)"""
 import os, sys
+os.environ.setdefault("PFAC_ENABLE_KNOBS", "1")     # tuning / test knobs of libpfac_hip.so are opt-in
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from phfpfac_amd import GpuMatcher, PfacTable

@@ -5,6 +5,7 @@ Looks for rare protocol failures (timeouts surface as PFAC_E_INTERNAL), count dr
 usage: soak.py [seconds] [seed] [own] [dict]      ("own": the two slots keep their own streams -> two grids at once;
 "dict": the 7 989-word dictionary instead of experimentpattern -- tables via L2, dense staging, four walks per lane)"""
 import os
+os.environ.setdefault("PFAC_ENABLE_KNOBS", "1")     # tuning / test knobs of libpfac_hip.so are opt-in
 import sys
 import time
 

@@ -1,6 +1,7 @@
 """GPU diagnostic: per-round timestamps of the coordinator and of compute wave 0 (trace build: make -C phfpfac_amd/csrc trace).
 usage: trace_rounds.py <pattern fixture | nomatch1> [text|rand]"""
 import os, sys
+os.environ.setdefault("PFAC_ENABLE_KNOBS", "1")     # tuning / test knobs of libpfac_hip.so are opt-in
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "trace.bin")
