@@ -820,20 +820,12 @@ __device__ __forceinline__ unsigned long long tile_pass(const ScanArgs &a, const
 // records (16 bytes) per lane per store, aligned to the record array; non-temporal stores -- the records are not read
 // again by this launch, and written through they do not pile up dirty in L2 until the kernel ends (measured: the same at
 // 1 GiB shards, +3.5 % at 4 GiB).
+template <bool SPARSE>
 __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stage, unsigned cnt, unsigned long long base, int lane) {
     if (cnt == 0) return;
 #ifdef PFAC_ABL_NOEMIT                         // ablation builds only: records never leave LDS
     return;
 #endif
-    if (cnt <= 2u * WAVE && a.rec_bytes == 4 && base + cnt <= a.out_cap) {
-        // a sparse tile (the L2-table workloads: tens of records): one record per lane per store, two independent trips
-        // -- the aligned 16-byte form below pays three dependent LDS round trips (head, body, tail) for a few hundred bytes
-        unsigned *out = static_cast<unsigned *>(a.out);
-        const unsigned v0 = (unsigned)lane < cnt ? stage[lane] : 0u, v1 = (unsigned)lane + WAVE < cnt ? stage[lane + WAVE] : 0u;
-        if ((unsigned)lane < cnt) __builtin_nontemporal_store(v0, out + base + lane);
-        if ((unsigned)lane + WAVE < cnt) __builtin_nontemporal_store(v1, out + base + lane + WAVE);
-        return;
-    }
     if (a.rec_bytes == 2) {
         // automata with at most 16 final states: the record is the low half of the staged word; eight per 16-byte store
         unsigned short *out = static_cast<unsigned short *>(a.out);
@@ -854,6 +846,15 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
         // the last 1..7 records: one lane each (not a loop in the one lane that stopped there: seven dependent LDS trips)
         const unsigned tail = head + ((cnt - head) & ~7u);
         if (tail + (unsigned)lane < cnt) out[base + tail + lane] = (unsigned short)stage[tail + lane];
+        return;
+    }
+    if (SPARSE && cnt <= 2u * WAVE && base + cnt <= a.out_cap) {
+        // a sparse tile (the L2-table workloads: tens of records): one record per lane per store, two independent trips
+        // -- the aligned 16-byte form below pays three dependent LDS round trips (head, body, tail) for a few hundred bytes
+        unsigned *out = static_cast<unsigned *>(a.out);
+        const unsigned v0 = (unsigned)lane < cnt ? stage[lane] : 0u, v1 = (unsigned)lane + WAVE < cnt ? stage[lane + WAVE] : 0u;
+        if ((unsigned)lane < cnt) __builtin_nontemporal_store(v0, out + base + lane);
+        if ((unsigned)lane + WAVE < cnt) __builtin_nontemporal_store(v1, out + base + lane + WAVE);
         return;
     }
     unsigned *out = static_cast<unsigned *>(a.out);
@@ -1228,7 +1229,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                 unsigned long long base = 0;
                 const bool okb = record_base(r - lag, base);
                 PFAC_STAMP(trace, 9);
-                if (okb) copy_out(a, stage0 + (buf + 1u == nbuf ? 0u : buf + 1u) * a.stage_cap, n_rec, base, lane);
+                if (okb) copy_out<!TLDS>(a, stage0 + (buf + 1u == nbuf ? 0u : buf + 1u) * a.stage_cap, n_rec, base, lane);
             }
         };
         if (NB == 3) emit_pending(pend_have[LAG_MAX - 1], pend_cnt[LAG_MAX - 1]);      // stores right behind the loads
@@ -1385,7 +1386,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
                 // while its bytes are still in LDS, writing straight to global memory
                 tile_pass<W8, true, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, base);
             else
-                copy_out(a, stage, (unsigned)cnt, base, lane);   // dense mode: staged, emitted at once
+                copy_out<!TLDS>(a, stage, (unsigned)cnt, base, lane);   // dense mode: staged, emitted at once
         }
         if (NB == 2) emit_pending(pend_have[0], pend_cnt[0]);
         PFAC_STAMP(trace, 8);
@@ -1414,7 +1415,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         if ((unsigned)k < lag && pend_have[k] && pend_cnt[k] != 0) {
             unsigned long long base = 0;
             if (record_base(r - (unsigned)k, base))
-                copy_out(a, stage0 + ((buf + nbuf - 1u - (unsigned)k) % nbuf) * a.stage_cap, pend_cnt[k], base, lane);
+                copy_out<!TLDS>(a, stage0 + ((buf + nbuf - 1u - (unsigned)k) % nbuf) * a.stage_cap, pend_cnt[k], base, lane);
         }
     }
 }

@@ -30,5 +30,6 @@ with GpuMatcher(0, 1) as g:
         try: g.scan_finish(0, allow_overflow=True)
         except Exception as e: print("finish:", e)
         ms.append(g.elapsed_ms(0))
+half = np.array(ms[len(ms) // 2:])
 tail = np.array(ms[-16:])
-print(f"{os.path.basename(os.environ.get('PFAC_HIP_LIB', 'product'))} {name} {sys.argv[2] if len(sys.argv) > 2 else 'text'}: last16 mean {tail.mean():.4f} ms = {N / tail.mean() / 1e6:.0f} GB/s, min {tail.min():.4f} ms = {N / tail.min() / 1e6:.0f} GB/s")
+print(f"{os.path.basename(os.environ.get('PFAC_HIP_LIB', 'product'))} {name} {sys.argv[2] if len(sys.argv) > 2 else 'text'}: last16 mean {tail.mean():.4f} ms = {N / tail.mean() / 1e6:.0f} GB/s, min {tail.min():.4f} ms = {N / tail.min() / 1e6:.0f} GB/s; second half of {len(ms)} launches: mean {half.mean():.4f} ms = {N / half.mean() / 1e6:.0f} GB/s")
