@@ -1057,3 +1057,24 @@ def test_knobs_are_opt_in(resolve):
     off = subprocess.run([sys.executable, "-c", code], env=dict(base, PFAC_FORCE_L2="1", PFAC_FAULT="1"), capture_output=True, text=True, check=True)
     on = subprocess.run([sys.executable, "-c", code], env=dict(base, PFAC_FORCE_L2="1", PFAC_ENABLE_KNOBS="1"), capture_output=True, text=True, check=True)
     assert off.stdout.split()[-1] == "tables_in_lds" and on.stdout.split()[-1] == "tables_via_l2"
+
+
+@pytest.mark.parametrize("ingest", ["mmap", "pread"])
+def test_gphf_edge_sizes(ingest, resolve, tmp_path):
+    """The CLI on degenerate and boundary-sized inputs, both ingest paths: an empty file, one and two bytes (N = size - 1,
+    main.cc:138), sizes around a page, around one chunk and around a registration piece boundary (PFAC_CHUNK_MB=1: a piece
+    is 256 chunks), a file whose last chunk is one byte long."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "phfpfac_amd", "bin", "gphf")
+    para = open(resolve("paragraph402"), "rb").read()
+    o = Oracle(resolve("xaa"), 1, 1)
+    env = dict(os.environ, PFAC_CHUNK_MB="1", PFAC_INGEST=ingest, PFAC_READ_THREADS="3")
+    for size in (0, 1, 2, 5, 4095, 4096, 4097, (1 << 20), (1 << 20) + 1, (1 << 20) + 2, 3 * (1 << 20) + 17):
+        f = tmp_path / f"in_{size}"
+        f.write_bytes(tiled_bytes(size, para).tobytes())
+        r = subprocess.run([exe, resolve("xaa"), "2", "256", str(f)], cwd=tmp_path, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, (size, r.stderr[-500:])
+        exp = tmp_path / "expected.txt"
+        o.emit(tiled_bytes(max(size - 1, 0), para), str(exp), spec=True)
+        assert (tmp_path / "GPU_match_result.txt").read_bytes() == exp.read_bytes(), size
+    o.close()
