@@ -37,6 +37,12 @@ from .table import RECORD_DTYPE, PfacTable, merge_partitions
 ALIGN = 16
 
 
+def _wire(device: torch.device) -> torch.device:
+    """Where tensors live while they travel: the device itself over RCCL ("nccl"), host memory over gloo (whose
+    point-to-point operations take CPU tensors only) -- results are moved back to ``device`` by the callers."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """Owned start-offset range of ``rank``: contiguous, cut at multiples of 16 bytes."""
     per = -(-n_total // world)
@@ -59,7 +65,8 @@ def broadcast_table(table: Optional[PfacTable], device: torch.device, src: int =
     r + HT + val + idmap, <= ~17 MiB for the largest pattern sets) -- a single broadcast over xGMI.
     """
     rank = dist.get_rank()
-    n = torch.zeros(1, dtype=torch.int64, device=device)
+    wire = _wire(device)
+    n = torch.zeros(1, dtype=torch.int64, device=wire)
     blob_host = None
     if rank == src:
         if table is None:
@@ -69,20 +76,21 @@ def broadcast_table(table: Optional[PfacTable], device: torch.device, src: int =
     dist.broadcast(n, src)
     words = int(n.item())
     if rank == src:
-        blob = torch.from_numpy(blob_host).to(device)
+        blob = torch.from_numpy(blob_host).to(wire)
     else:
-        blob = torch.empty(words, dtype=torch.int32, device=device)
+        blob = torch.empty(words, dtype=torch.int32, device=wire)
     dist.broadcast(blob, src)
     if rank != src:
         table = PfacTable.from_blob(blob.cpu().numpy())
-    return blob, table
+    return blob.to(device), table
 
 
 def gather_counts(n_local: int, device: torch.device) -> List[int]:
     """All-gather of one int64 per rank: every rank learns every shard's match count."""
     world = dist.get_world_size()
-    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
-    parts = [torch.empty(1, dtype=torch.int64, device=device) for _ in range(world)]
+    wire = _wire(device)
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=wire)
+    parts = [torch.empty(1, dtype=torch.int64, device=wire) for _ in range(world)]
     dist.all_gather(parts, mine)
     return [int(p.item()) for p in parts]
 
@@ -151,7 +159,8 @@ def gather_packed_tensors(words: torch.Tensor, tile_index: torch.Tensor, rec_byt
     ``pfac_emit_packed`` prints a rank's part as it is (``emit_gathered``); ``packed_to_records`` expands it.
     Works on CPU tensors with gloo as well (tests/test_dist_cpu.py)."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    device = words.device
+    device = _wire(words.device)
+    words, tile_index = words.to(device), tile_index.to(device)
     mine = torch.tensor([int(words.numel()), int(tile_index.numel()), int(rec_bytes), int(n_matches)], dtype=torch.int64, device=device)
     meta = torch.empty(world * 4, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(meta, mine)
