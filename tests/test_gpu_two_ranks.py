@@ -1,4 +1,4 @@
-"""Two RANKS on hardware (run with -m gpu): the N > 1 path of phfpfac_amd/dist.py with real scans.
+"""Two (and four) RANKS on hardware (run with -m gpu): the N > 1 path of phfpfac_amd/dist.py with real scans.
 
 The builder's box has ONE MI355X, and RCCL refuses two ranks on one device, so the two processes of this test share
 cuda:0 and talk over `gloo` (which carries device tensors): everything but the transport is what `bench.py --gpus 2`
@@ -73,14 +73,14 @@ def _rank(rank, world, port, pat_path, n_total, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pattern,kind,n_total", [("xaa", "text", (24 << 20) + 12345), ("experimentpattern", "text", (64 << 20) + 7),
-                                                   ("bytefile_10000byte", "rand", (16 << 20) + 401)])
-def test_two_ranks_sharded_scan_on_the_gpu(pattern, kind, n_total, tmp_path):
+@pytest.mark.parametrize("world,pattern,kind,n_total", [(2, "xaa", "text", (24 << 20) + 12345), (2, "experimentpattern", "text", (64 << 20) + 7),
+                                                         (2, "bytefile_10000byte", "rand", (16 << 20) + 401), (4, "xaa", "text", (24 << 20) + 999)])
+def test_two_ranks_sharded_scan_on_the_gpu(world, pattern, kind, n_total, tmp_path):
     import torch.multiprocessing as mp
     from orc import Oracle
     from phfpfac_amd.matcher import splitmix64_bytes, tiled_bytes
     pat_path = os.path.join(DATA, pattern)
-    mp.spawn(_rank, args=(2, _free_port(), pat_path, n_total, kind, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank, args=(world, _free_port(), pat_path, n_total, kind, str(tmp_path)), nprocs=world, join=True)
     rec = np.load(tmp_path / "rec.npy")
     idmap = np.load(tmp_path / "idmap.npy")
     para = open(os.path.join(DATA, "paragraph402"), "rb").read()
@@ -95,7 +95,7 @@ def test_two_ranks_sharded_scan_on_the_gpu(pattern, kind, n_total, tmp_path):
     o.close()
     assert (tmp_path / "gathered.txt").read_bytes() == exp.read_bytes()
     # the cut between the shards lies inside the stream: matches start on both sides of it
-    cut = -(-n_total // 2)
+    cut = -(-n_total // world)
     cut = (cut + 15) // 16 * 16
     if pos.size > 100:
         assert (pos < cut).any() and (pos >= cut).any()
