@@ -494,21 +494,34 @@ __device__ __forceinline__ void walkN(const unsigned char *tile, const int *s0, 
     };
     if (!reached(1, false)) return;
     if (dense1) {
-        // second byte: the depth-1 state's row is dense in LDS -- one lookup, no hash, no owner check
+        // second byte: the depth-1 state's row is dense in LDS -- one lookup, no hash, no owner check.  Stage by stage for
+        // all the walks of the lane (column, row entry, packed r[] / child mask): written walk by walk, the uniform test on
+        // D1R2 put every walk into basic blocks of its own and their LDS round trips in SERIES -- six trips instead of three
+        unsigned col[NWALK];
+        int nx[NWALK];
 #pragma unroll
-        for (int w = 0; w < NWALK; w++) {
-            const int nx = D1[(go[w] ? f[w] : 0u) * d1_stride + colmap[(win[w] >> 8) & 0xFFu]];
-            if (FUSED && D1R2) {
-                // packed entry: the depth-2 state and where its r[] sits in LDS -- the walk's first hashed step
-                // needs no r[] gather either
-                const bool ok = go[w] && nx >= 0;
-                s[w] = ok ? (nx & ((1 << D1_STATE_BITS) - 1)) : -1;
-                const int2 e2 = D1R2[ok ? (nx >> D1_STATE_BITS) : 0];      // {r[] of the depth-2 state, its child mask}
-                rn[w] = e2.x;
-                cm[w] = (unsigned)e2.y;
-            } else {
-                s[w] = go[w] ? nx : -1;
+        for (int w = 0; w < NWALK; w++) col[w] = colmap[(win[w] >> 8) & 0xFFu];
+#pragma unroll
+        for (int w = 0; w < NWALK; w++) nx[w] = D1[(go[w] ? f[w] : 0u) * d1_stride + col[w]];
+        if (FUSED && D1R2) {
+            // packed entry: the depth-2 state and where its r[] sits in LDS -- the walk's first hashed step needs no r[]
+            // gather either
+            bool ok[NWALK];
+            int2 e2[NWALK];
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) {
+                ok[w] = go[w] && nx[w] >= 0;
+                e2[w] = D1R2[ok[w] ? (nx[w] >> D1_STATE_BITS) : 0];        // {r[] of the depth-2 state, its child mask}
             }
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) {
+                s[w] = ok[w] ? (nx[w] & ((1 << D1_STATE_BITS) - 1)) : -1;
+                rn[w] = e2[w].x;
+                cm[w] = (unsigned)e2[w].y;
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < NWALK; w++) s[w] = go[w] ? nx[w] : -1;
         }
         k++;
     } else {
