@@ -480,6 +480,7 @@ static void *worker(void *arg) {
     uint64_t *cap = NULL;
     int *busy = NULL;               /* chunk index occupying each slot, or -1 */
     int freed = 0;                  /* this worker's chunks [0, freed) have given their staging buffers back */
+    int issued = 0;                 /* ... and [0, issued) have had their H2D copies issued */
     const double ts = now_ms();
     int rc = pfac_ctx_create(w->device, w->n_streams, &ctx);
     if (rc) {
@@ -609,7 +610,7 @@ static void *worker(void *arg) {
             if (w->ingest_mmap) piece_copy_done(c->base);
             pthread_mutex_lock(&g_mu);
             if (!w->ingest_mmap) st->state = ST_FREE;
-            freed = j + 1;
+            freed = issued = j + 1;
             schedule_reads(w);
             pthread_mutex_unlock(&g_mu);
             chunk_done(c);
@@ -633,6 +634,7 @@ static void *worker(void *arg) {
         w->issue_h2d_ms += ti2 - ti;
         w->issue_scan_ms += now_ms() - ti2;
         busy[slot] = k;
+        issued = j + 1;
     }
     for (int s = 0; s < w->n_streams && !w->rc; s++) {      /* drain what is still in flight, oldest first */
         int lowest = -1;
@@ -646,8 +648,9 @@ out:
     MILESTONE("worker %d: last chunk drained", w->index);
     if (w->rc) set_failed();
     pool_wait_idle(&g_readers);     /* no reader may still write into the staging buffers freed below */
-    if (w->ingest_mmap && !w->rc)       /* every scan has been waited for, so every copy has completed: the last pieces */
-        for (; freed < w->n_mine; freed++) piece_copy_done(w->chunks[w->index + freed * w->n_workers].base);
+    if (w->ingest_mmap && !w->rc && !g_failed)      /* every scan has been waited for, so every copy has completed: the last pieces
+                                                      * (only chunks whose copy was issued: unregistering what never was registered aborts in the runtime) */
+        for (; freed < issued; freed++) piece_copy_done(w->chunks[w->index + freed * w->n_workers].base);
     for (int b = 0; b < w->n_stage; b++) pfac_host_free(w->stage[b].buf);
     pfac_host_free(w->halo_buf);
     free(cap); free(busy);
