@@ -20,11 +20,22 @@ within 1.5 % and sit within 2 % of the fastest launch seen (a cold GPU's first l
 clocks ramp, with intermediate plateaus); its length and the cold figure are reported in `config` (`settle_launches`,
 `cold_first20_gbs`).
 
+Parity, outside the timed region, for EVERY workload timed and on every rank: the GPU's (match count, record checksum) of
+the whole resident shard == one serial Aho-Corasick pass over the bytes copied back from HBM (tests/orc.py: ac_whole_shard),
+plus the records of the first 1 MiB one by one, in order, against the oracle's PFAC walk.
+
 One JSON line is printed by rank 0 (contract in the task statement) with extra objects:
   roofline         algorithmic bytes (1 B per input byte) / kernel time measured with HIP events on the stream the kernel
                    runs on, against the 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch from the committed rocprofv3
                    PMC passes when they were taken from this very kernel source (else null), `traffic_model` = input +
                    records + tile index bytes computed from this run
+  sustained        the same scan back to back for --sustain-seconds (default 2.5 s, ~11 000 launches): mean / p5 / p50 / p95 of
+                   the per-launch kernel rate and the wall-clock rate -- what a long job sees, next to the K-step `value`
+  end_to_end       BASELINE configs[2], PCIe inclusive: 4 GiB in pinned host memory -> four slots on four streams
+                   (hipMemcpyAsync H2D || scan) -> counts (N = 1 only; never reported as `value`)
+  config.*_ms      what an ordered / host / text consumer pays on top of the scan, each outside the timed region: expand_ms
+                   (heap -> sorted 8-byte records on the device), readback_ms (compact form D2H), emit_text_ms (GPU-side text
+                   emitter), gather_ms (N > 1: compact records to rank 0 over RCCL)
   cpu_baseline     serial Aho-Corasick (oracle/ac_serial.c, the CHECKER, kind "port") on ONE host core, bounded sample;
                    cpu_baseline_pfac (the oracle's PFAC-on-CPU walk, one core) and cpu_baseline_threads (serial AC on
                    all the cores this process may use) next to it (N = 1 only)
