@@ -15,9 +15,9 @@ tmp = tempfile.mkdtemp()
 KNOBS = [{}, {"PFAC_FORCE_L2": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_DENSE": "1"}, {"PFAC_DENSE": "1"}, {"PFAC_LAG": "1"},
          {"PFAC_LAG": "2"}, {"PFAC_FORCE_L2": "1", "PFAC_NO_FUSE": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_NO_D1": "1"},
          {"PFAC_REC_BYTES": "4"}, {"PFAC_WIDE": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_NO_NW4": "1", "PFAC_DENSE": "1"},
-         {"PFAC_L2F": "0"}, {"PFAC_L2F": "2"}, {"PFAC_NO_SECF": "1", "PFAC_FORCE_L2": "1"}, {"PFAC_NWB": "4"}]
+         {"PFAC_L2F": "0"}, {"PFAC_L2F": "2"}, {"PFAC_L2F": "3"}, {"PFAC_L2F": "3", "PFAC_FORCE_L2": "1"}, {"PFAC_NO_SECF": "1", "PFAC_FORCE_L2": "1"}, {"PFAC_NWB": "4"}]
 ALL = sorted({k for d in KNOBS for k in d})
-t0 = time.time(); cases = 0; recs = 0
+t0 = t_last = time.time(); cases = 0; recs = 0
 while time.time() - t0 < seconds:
     alpha = int(rng.choice([2, 3, 4, 8, 26, 60, 200]))
     symbols = rng.permutation(np.array([b for b in range(256) if b != 10], dtype=np.uint8))[:alpha]
@@ -52,5 +52,13 @@ while time.time() - t0 < seconds:
             if not (rec.size == pos.size and np.array_equal(rec["pos"].astype(np.int64), pos) and np.array_equal(table.idmap[rec["state"]], ids)):
                 raise SystemExit(f"MISMATCH case {cases} rep {rep}: seed {seed} alpha {alpha} npat {len(pats)} maxlen {maxlen} width {width} knobs {knobs} n {n} n_owned {n_owned}: got {rec.size} want {pos.size} (pattern file {pf})")
             recs += int(pos.size)
+            if rep == 1 and pos.size < 400000:             # the GPU-side text emitter against lines formatted here
+                base = int(rng.choice([0, 999_999_990, 3 << 32]))
+                text = g.text_to_host(g.emit_text_device(base))
+                want = "".join("At position %4d, match pattern %d\n" % (p + base, i) for p, i in zip(pos.tolist(), ids.tolist())).encode()
+                if text != want:
+                    raise SystemExit(f"TEXT MISMATCH case {cases}: seed {seed} knobs {knobs} n {n} n_owned {n_owned} base {base}: {len(text)} bytes, want {len(want)} (pattern file {pf})")
     os.remove(pf); cases += 1
+    if time.time() - t_last > 30:
+        t_last = time.time(); print(f"  ... {cases} cases, {recs} records compared, {t_last - t0:.0f} s", flush=True)
 print(f"fuzz ok: {cases} cases in {time.time() - t0:.0f} s (seed {seed}), {recs} records compared")
