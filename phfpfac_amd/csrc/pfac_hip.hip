@@ -122,6 +122,16 @@ constexpr int PW_FIXED_1BUF = WTILE + QCAP * 2;              // + nbuf * stage_c
 // wave and synchronous emission -- fewer waves fit, but a tile is walked once instead of twice.
 constexpr int CAPW_DENSE = 2048;
 constexpr int PW_FIXED_DENSE = PW_FIXED_1BUF + CAPW_DENSE * 4;
+// Dense mode, second form (dense2_tile below: walker slots refilled the moment a walk ends, records logged out of order
+// and put in order on their way out).  Per wave, behind the tile + halo: ring of pending walkers | match count of every
+// tile position (4 bits each) | record prefix of every 8 positions (u16).
+constexpr int D2_RING = 256;               // ring entries of 8 bytes (a power of two, >= 3 front-end batches of 64)
+constexpr int D2_CNT_OFF = D2_RING * 8;
+constexpr int D2_PREF_OFF = D2_CNT_OFF + WTILE / 2;
+constexpr int D2_AUX = D2_PREF_OFF + (WTILE / 8) * 2;
+static_assert(D2_AUX >= QCAP * 2 && D2_AUX % 16 == 0, "the survivor FIFO of the fallback pass lies in the same bytes");
+constexpr int PW_FIXED_DENSE2 = WTILE + D2_AUX;              // (the record log is in device memory)
+constexpr unsigned D2_LOG_CAP = 4096;     // words of log per wave (device memory; a tile with more records goes the classic way)
 
 // Batch tickets: one address sustains ~85 M atomics/s, and at 4 TB/s with 60 KiB per ticket the workgroups ask for
 // 65 M/s -- the single counter was the floor of the whole kernel (3.9 us per round with the scan compiled out).  So
@@ -182,6 +192,9 @@ struct ScanArgs {
     int sec_filter;                       // ROOT == 0, mode 2: pre-filter the lookups with sec2 (no 1-byte patterns)
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
     unsigned nbuf;                        // staging buffers per wave: 3 / 2 = emit two / one round(s) later, 1 = emit at once (dense mode)
+    int dense2;                           // dense mode on fused tables with packed dense rows: the refilled-walker form (dense2_tile)
+    unsigned *d2log;                      // ... its record logs: d2log_cap words per compute wave of the grid (device memory)
+    unsigned d2log_cap;
     unsigned sparse_cap;                  // tiles with more matches than this are counted in res[3] (mode adaptation) ...
     unsigned small_cap;                   // ... and than this (the three-buffer capacity) in res[6]
     unsigned n_tiles;
@@ -888,6 +901,234 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
     if (tail + (unsigned)lane < cnt) out[base + tail + lane] = stage[tail + lane];
 }
 
+// ---------------------------------------------------------------------------
+// Dense mode, second form (a dictionary on text: most offsets start a walk, every third goes beyond its second byte).
+// tile_pass runs its walkers in rounds of 256, in lock step to the depth of the round's deepest walker -- on text a
+// fifth of the lane-steps of such a round belong to a live walker -- because a round's records have to come out in
+// (position, length) order, and its 8 KiB staging buffer per wave leaves room for 9 waves per CU.  Here the order is
+// made afterwards, and the records wait in device memory, not in LDS (15 waves per CU):
+//   * front end, D2_FB x 64 consecutive positions per trip, every lane busy: first state (root row), second state (dense
+//     row of the depth-1 state: s0 / d1idx / colmap -> rows -> packed {r[], child mask}: three dependent LDS trips), their
+//     final states logged at once; the positions whose depth-2 state has an edge on a byte congruent to the third one
+//     (child mask) go into a ring of pending walkers {position, state, r[], records so far};
+//   * four walker slots per lane; a slot whose walk has ended takes the next ring entry, so the gathers of a step
+//     belong to live walkers only; a walker dies WITHOUT the gather that would say so when the child mask of its state
+//     has no bit for the next byte; every final state is logged as {position, k-th record of the position, state};
+//   * the log is the wave's own scratch in device memory (written 64 words at a time, read back once: it stays in L2);
+//   * once the tile is done the log is read twice: the records of every position are counted (4-bit fields in LDS), the
+//     counts prefix-summed (per 8 positions + a nibble sum inside the word), and every log entry is stored straight to
+//     its place in the heap: base + prefix[position] + k.
+// Log full or more than 15 patterns starting at one offset: the tile is done again by tile_pass (returns ~0u), counted
+// and then written directly (no staging buffer in this layout).  Needs: fused tables, packed dense rows (every depth-1
+// state has a dense row, every depth-2 state an entry in d1.r2), final states below 2^16, 4-byte records.
+constexpr int D2_FB = 2;                       // front-end batches per trip (their LDS round trips overlap)
+static_assert(D2_RING >= (D2_FB + 1) * WAVE, "ring: one trip's pushes on top of a batch of left-overs");
+template <bool W8>
+__device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
+                                                unsigned char *aux, unsigned *logg, int lane, unsigned lim, unsigned own_end) {
+    constexpr int NS = 4;                      // walker slots per lane
+    uint2 *ring = reinterpret_cast<uint2 *>(aux);
+    const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
+    const int sub = a.wbit - 8;
+    const unsigned nfin = (unsigned)a.num_final, logcap = a.d2log_cap;
+    // the log through a buffer descriptor: a scalar base, one shift per store, and a store past the end is dropped
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(logg, 0, (int)(logcap * 4u), 0x00020000);
+    unsigned pos[NS], pn[NS], jn[NS];          // position; index of the byte the next gather consumes; records of the position so far
+    int s[NS], idx[NS];                        // state; fused slot the next gather reads (r[row of state] + column of that byte)
+    bool alive[NS];
+#pragma unroll
+    for (int w = 0; w < NS; w++) { pos[w] = pn[w] = jn[w] = 0u; s[w] = -1; idx[w] = 0; alive[w] = false; }
+    unsigned P0 = 0, head = 0, fcount = 0, lc = 0;             // wave-uniform: next front-end position, ring, log fill
+    unsigned jmax = 0;
+    auto lane_rank = [&](unsigned long long b) -> unsigned {
+        return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    };
+    auto log_put = [&](bool f, unsigned word) {
+        const unsigned long long b = __ballot(f);
+        if (b) {
+            if (f) __builtin_amdgcn_raw_buffer_store_b32(word, lrs, (int)((lc + lane_rank(b)) << 2), 0, 0);
+            lc += (unsigned)__popcll(b);
+        }
+    };
+    auto slot = [&](int i) -> int4 {
+        return *reinterpret_cast<const int4 *>(reinterpret_cast<const unsigned char *>(a.T4) + ((unsigned)i << 4));
+    };
+    auto slot_of = [&](int rnv, unsigned st, unsigned byte) -> int {       // fused slot of (state, byte), r[row of state] given
+        return W8 ? rnv + (int)byte : rnv + (int)(((st & ((1u << sub) - 1u)) << 8) | byte);
+    };
+    for (;;) {
+        unsigned long long dm[NS];
+        unsigned nd = 0;
+#pragma unroll
+        for (int w = 0; w < NS; w++) { dm[w] = __ballot(!alive[w]); nd += (unsigned)__popcll(dm[w]); }
+        // ---- front end: as many trips as the free slots ask for
+        while (fcount < nd && P0 < own_end && fcount <= (unsigned)(D2_RING - D2_FB * WAVE)) {
+            unsigned p[D2_FB], win[D2_FB], row[D2_FB], col[D2_FB], s2[D2_FB];
+            int s1[D2_FB], nx[D2_FB];
+            int2 e2[D2_FB];
+            bool a2[D2_FB];
+#pragma unroll
+            for (int u = 0; u < D2_FB; u++) {
+                p[u] = P0 + (unsigned)(u * WAVE + lane);
+                const unsigned lo = t32[p[u] >> 2], hi = t32[(p[u] >> 2) + 1];
+                win[u] = __builtin_amdgcn_alignbyte(hi, lo, p[u] & 3u);          // bytes p .. p+3
+            }
+#pragma unroll
+            for (int u = 0; u < D2_FB; u++) {
+                s1[u] = s0[win[u] & 0xFFu];
+                row[u] = d1.idx[win[u] & 0xFFu];
+                col[u] = d1.colmap[(win[u] >> 8) & 0xFFu];
+            }
+#pragma unroll
+            for (int u = 0; u < D2_FB; u++) {
+                if (p[u] >= own_end) s1[u] = -1;
+                nx[u] = d1.rows[row[u] * (unsigned)a.d1_stride + col[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < D2_FB; u++) {
+                a2[u] = s1[u] >= 0 && p[u] + 1u < lim && nx[u] >= 0;
+                e2[u] = d1.r2[a2[u] ? (nx[u] >> D1_STATE_BITS) : 0];             // {r[] of the depth-2 state, its child mask}
+                s2[u] = (unsigned)nx[u] & ((1u << D1_STATE_BITS) - 1u);
+            }
+#pragma unroll
+            for (int u = 0; u < D2_FB; u++) {
+                const bool fin1 = (unsigned)s1[u] < nfin, fin2 = a2[u] && s2[u] < nfin;
+                const unsigned b2 = (win[u] >> 16) & 0xFFu;
+#ifdef PFAC_ABL_D2NOWALK                       // ablation builds only: nothing goes beyond its second byte (records missing)
+                const bool more = false && a2[u];
+#else
+                const bool more = a2[u] && p[u] + 2u < lim && (((unsigned)e2[u].y >> (b2 & 31u)) & 1u) != 0u;
+#endif
+                log_put(fin1, p[u] | ((unsigned)s1[u] << 16));
+                log_put(fin2, p[u] | (fin1 ? 1u << 12 : 0u) | (s2[u] << 16));
+                const unsigned long long mb = __ballot(more);
+                if (mb) {
+                    const unsigned n12 = (fin1 ? 1u : 0u) + (fin2 ? 1u : 0u);
+                    if (more) ring[(head + fcount + lane_rank(mb)) & (unsigned)(D2_RING - 1)] =
+                        make_uint2(p[u] | (s2[u] << 12), (unsigned)slot_of(e2[u].x, s2[u], b2) | (n12 << 28));
+                    fcount += (unsigned)__popcll(mb);
+                }
+            }
+            P0 += D2_FB * WAVE;
+        }
+        if (nd == (unsigned)(NS * WAVE) && fcount == 0u) break;        // no walker left, none pending, every position seen
+        wave_lds_sync();
+        // ---- free slots take the pending walkers
+#pragma unroll
+        for (int w = 0; w < NS; w++) {
+            if (fcount && dm[w]) {
+                const unsigned free_n = (unsigned)__popcll(dm[w]);
+                const unsigned take = free_n < fcount ? free_n : fcount;
+                const unsigned rk = lane_rank(dm[w]);
+                if (!alive[w] && rk < take) {
+                    const uint2 e = ring[(head + rk) & (unsigned)(D2_RING - 1)];
+                    pos[w] = e.x & 0xFFFu;
+                    s[w] = (int)(e.x >> 12);
+                    idx[w] = (int)(e.y & 0x0FFFFFFFu);
+                    jn[w] = e.y >> 28;
+                    pn[w] = pos[w] + 2u;
+                    alive[w] = true;
+                }
+                head += take;
+                fcount -= take;
+            }
+        }
+        // ---- one transition of every live walker
+        int4 e4[NS];
+        unsigned nb[NS];
+#pragma unroll
+        for (int w = 0; w < NS; w++) {
+            e4[w] = make_int4(-1, -1, 0, 0);
+            if (alive[w]) e4[w] = slot(idx[w]);
+        }
+#pragma unroll
+        for (int w = 0; w < NS; w++) nb[w] = tile[alive[w] ? pn[w] + 1u : 0u];     // the byte after (at most one past lim: not used then)
+#pragma unroll
+        for (int w = 0; w < NS; w++) {
+            const bool ok = alive[w] && e4[w].x == (W8 ? s[w] : (s[w] >> sub));
+            const int sn = e4[w].y;
+            const bool fin = ok && (unsigned)sn < nfin;
+            log_put(fin, pos[w] | ((jn[w] & 15u) << 12) | ((unsigned)sn << 16));
+            jn[w] += fin ? 1u : 0u;
+            jmax |= jn[w];                     // (bit 4 or above: a 16th record at one position)
+            pn[w] += 1u;
+            alive[w] = ok && pn[w] < lim && (((unsigned)e4[w].w >> (nb[w] & 31u)) & 1u) != 0u;
+            s[w] = sn;
+            idx[w] = slot_of(e4[w].z, (unsigned)sn, nb[w]);
+        }
+    }
+    if (__any(jmax > 15u) || lc > logcap) return ~0u;
+    return lc;
+}
+
+// The tile's log -> its place in the record heap (4-byte records), in (position, length) order: the records of every
+// position are counted (4-bit fields), the counts prefix-summed, and every log entry goes to base + prefix[position] + k.
+__device__ __forceinline__ void dense2_scatter(const ScanArgs &a, unsigned char *aux, const unsigned *logg, unsigned cnt,
+                                               unsigned long long base, int lane) {
+    unsigned *cntw = reinterpret_cast<unsigned *>(aux + D2_CNT_OFF);
+    unsigned *pref2 = reinterpret_cast<unsigned *>(aux + D2_PREF_OFF);            // u16 pairs
+    const unsigned short *pref = reinterpret_cast<const unsigned short *>(aux + D2_PREF_OFF);
+    auto nibsum = [](unsigned x) -> unsigned { return (((x & 0x0F0F0F0Fu) + ((x >> 4) & 0x0F0F0F0Fu)) * 0x01010101u) >> 24; };
+    constexpr int UN = 4;                      // log words in flight per lane
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4 *>(cntw)[lane] = zero4;
+    reinterpret_cast<u32x4 *>(cntw)[lane + WAVE] = zero4;
+    // (the log was written by other lanes of THIS wave: the workgroup-scope fence waits for their stores, and a CU's L1 is
+    // coherent with the stores of its own waves -- an agent-scope release would write the whole L2 back, per tile)
+    wave_lds_sync();
+    for (unsigned i0 = 0; i0 < cnt; i0 += UN * WAVE) {
+        unsigned e[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned i = i0 + (unsigned)(u * WAVE + lane);
+            e[u] = i < cnt ? logg[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned i = i0 + (unsigned)(u * WAVE + lane);
+            if (i < cnt) atomicAdd(&cntw[(e[u] & 0xFFFu) >> 3], 1u << ((e[u] & 7u) * 4u));
+        }
+    }
+    wave_lds_sync();
+    const u32x4 x0 = reinterpret_cast<const u32x4 *>(cntw)[2 * lane], x1 = reinterpret_cast<const u32x4 *>(cntw)[2 * lane + 1];
+    unsigned sm[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { sm[k] = nibsum(x0[k]); sm[4 + k] = nibsum(x1[k]); }
+    unsigned tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += sm[k];
+    unsigned run = wave_incl_scan(tot) - tot;
+    u32x4 pw;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned lo = run; run += sm[2 * k];
+        const unsigned hi = run; run += sm[2 * k + 1];
+        pw[k] = lo | (hi << 16);
+    }
+    reinterpret_cast<u32x4 *>(pref2)[lane] = pw;
+    wave_lds_sync();
+    unsigned *out = static_cast<unsigned *>(a.out);
+#ifdef PFAC_ABL_D2NOSCATTER                    // ablation builds only: the records never reach the heap
+    cnt = 0;
+#endif
+    for (unsigned i0 = 0; i0 < cnt; i0 += UN * WAVE) {
+        unsigned e[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned i = i0 + (unsigned)(u * WAVE + lane);
+            e[u] = i < cnt ? logg[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned i = i0 + (unsigned)(u * WAVE + lane);
+            const unsigned p = e[u] & 0xFFFu, j = (e[u] >> 12) & 15u, st = e[u] >> 16;
+            const unsigned x = cntw[p >> 3];
+            const unsigned dest = (unsigned)pref[p >> 3] + nibsum(x & ((1u << ((p & 7u) * 4u)) - 1u)) + j;
+            if (i < cnt && base + dest < a.out_cap) out[base + dest] = p | (st << 12);
+        }
+    }
+}
+
 // Root test: 16-bit mask of the lane's 16 bytes that have an edge out of the root.
 //   ROOT == 1: exactly one such byte value -> exact SWAR compare, flags gathered with v_dot4
 //   ROOT == 0: one LDS lookup per byte in pre-shifted flag tables (byte k of a dword looks into table k).  The same lookup
@@ -946,7 +1187,7 @@ __device__ __forceinline__ unsigned eq_mask32(const u32x4 lo16, const u32x4 hi16
 #ifndef PFAC_SPARSE_FUSED_NW
 #define PFAC_SPARSE_FUSED_NW 2
 #endif
-constexpr int MAX_WAVES_NW4 = 10;          // four walks per lane need registers: at most 10 waves per workgroup (dense mode has 9-10)
+constexpr int MAX_WAVES_NW4 = 10;          // four walks per lane, staged in LDS: dense mode's buffers leave room for 9-10 waves per workgroup
 
 template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB>
 __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem, const ErrCh &err) {
@@ -1145,7 +1386,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     // ================= compute waves =================
     unsigned char *tile = smem + a.shared_bytes + wave * a.pw_bytes;
     unsigned short *q = reinterpret_cast<unsigned short *>(tile + WTILE + a.halo);
-    unsigned *stage0 = reinterpret_cast<unsigned *>(tile + WTILE + a.halo + QCAP * 2);
+    const bool d2 = NW == 4 && FUSED && a.dense2 != 0;         // dense mode, second form (dense2_tile); its LDS carve differs
+    unsigned char *aux = tile + WTILE + a.halo;
+    unsigned *stage0 = reinterpret_cast<unsigned *>(aux + QCAP * 2);        // (d2: never written, stage_cap is 0)
+    unsigned *d2log = d2 ? a.d2log + ((size_t)blockIdx.x * (unsigned)nc + (unsigned)wave) * a.d2log_cap : nullptr;
     const bool root_final = ROOT == 1 && (unsigned)a.root_state < (unsigned)a.num_final;
 
     // prefetch registers: the wave's 4 KiB + halo, LOAD_DEPTH tiles ahead of the one being scanned (set A / set B)
@@ -1250,7 +1494,19 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 
         // ---- root test -> 32-bit survivor mask per lane per half-tile; level-2 filter -> which of them are kept
         // (yield a record or need a walk) and which of those are deep (need the walk)
-        unsigned keep[MSUBS], deep[MSUBS];
+        unsigned keep[MSUBS] = {0u, 0u}, deep[MSUBS] = {0u, 0u};
+        unsigned *stage = stage0 + buf * a.stage_cap;
+        // dense mode on fused tables with packed dense rows: no classification, no rounds (dense2_tile); a tile it gives
+        // up on (log full, > 15 patterns at one offset) goes the classic way below
+        unsigned d2cnt = ~0u;
+        if (NW == 4 && FUSED) {
+            if (d2) {
+                const unsigned long long own = a.n_owned - tile_base;
+                d2cnt = dense2_tile<W8>(a, tile, s0, d1, aux, d2log, lane, lim, own < (unsigned long long)WTILE ? (unsigned)own : (unsigned)WTILE);
+            }
+        }
+        const bool d2done = d2cnt != ~0u;
+        if (!d2done) {
 #pragma unroll
         for (int j = 0; j < MSUBS; j++) {
             const unsigned off = j * MSUB + lane * MLANE;
@@ -1347,6 +1603,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             PFAC_STAMP(trace && r > 0 && j == 0, 13);
 #endif
         }
+        }
 
 #ifdef PFAC_ABL_NOKEEP                         // ablation builds only: survivors classified, then dropped (no records)
         asm volatile("" :: "v"(keep[0]), "v"(keep[1]), "v"(deep[0]), "v"(deep[1]));
@@ -1354,9 +1611,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 #endif
         PFAC_STAMP(trace, 6);
         // ---- compact + walk once; records staged in LDS buffer `buf`; post the count
-        unsigned *stage = stage0 + buf * a.stage_cap;
         // (a tile nothing survives in -- most tiles of a sparse pattern set -- goes straight to posting its zero)
-        const unsigned long long cnt = !__any((keep[0] | keep[1]) != 0u) ? 0ull :
+        const unsigned long long cnt = d2done ? (unsigned long long)d2cnt : !__any((keep[0] | keep[1]) != 0u) ? 0ull :
             tile_pass<W8, false, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, 0);
         PFAC_STAMP(trace, 7);
 #ifdef PFAC_TRACE_BUILD
@@ -1394,7 +1650,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             const unsigned long long base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
                                             __builtin_amdgcn_readfirstlane((unsigned)v);
             if (lane == 0) a.tile_index[t] = base | ((unsigned long long)cnt << TIX_CNT_SHIFT);
-            if (overflow)
+            if (NW == 4 && FUSED && d2done)
+                dense2_scatter(a, aux, d2log, (unsigned)cnt, base, lane);
+            else if (overflow)
                 // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
                 // while its bytes are still in LDS, writing straight to global memory
                 tile_pass<W8, true, NW, FUSED, ROOT>(a, tile, s0, d1, R, T, q, stage, keep, deep, lane, lim, tile_base, base);
@@ -1434,7 +1692,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
 }
 
 template <bool TLDS, bool W8, int ROOT, bool FUSED, int NW, int NB = 2>
-__global__ __launch_bounds__(WAVE * (NW == 4 ? MAX_WAVES_NW4 : MAX_WAVES_PER_BLOCK)) void pfac_scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(WAVE * MAX_WAVES_PER_BLOCK) void pfac_scan_kernel(ScanArgs a) {
     static_assert(NB == 2 || (NB == 3 && NW <= 3), "three staging buffers: the sparse-mode kernels (dense mode has one)");
     static_assert(!(TLDS && FUSED), "the fused table is for tables gathered through L2");
     static_assert(NW == (TLDS ? 1 : 2) || (FUSED && (NW == 3 || NW == 4)), "walks per lane: 1 (LDS tables), 2 (L2 tables), 3 (L2, fused), 4 (L2, fused, dense matches)");
@@ -1855,6 +2113,8 @@ struct Slot {
     void *d_records = nullptr;            // record_cap x 8 bytes: holds either record format
     uint64_t record_cap = 0;
     unsigned long long *d_tile_index = nullptr;   // per tile of the last scan: first record | count << 40
+    unsigned *d_d2log = nullptr;                  // dense mode, second form: the record logs of the grid's compute waves
+    size_t d2log_words = 0;
     uint64_t tile_cap = 0;
     unsigned long long *d_gsum = nullptr; // scratch of the expand / text paths: record (byte) prefix per group of 64 tiles (+ the total)
     uint64_t gsum_cap = 0;
@@ -1919,6 +2179,7 @@ struct pfac_ctx {
     int pw_bytes_d = 0, waves_per_block_d = 0, lds_bytes_d = 0;
     unsigned stage_cap_d = 0;
     bool dense = false;                   // current staging mode (adapts to the match density seen by the last scan)
+    bool dense2 = false;                  // dense mode runs in its second form (dense2_tile): fused tables, packed dense rows, 4-byte records
     int dense_forced = -1;                // PFAC_DENSE=0/1 pins the mode
     int *d_d1 = nullptr;                  // dense depth-1 rows + (after them) the 256-byte row index
     int d1_rows = 0, d1_stride = 0, d1_ncols = 0, d1_lds_bytes = 0;
@@ -2206,7 +2467,9 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         ctx->lag2_ok = ctx->lag2 = false;
     }
     // dense-mode layout
-    ctx->pw_bytes_d = (int)align_up((size_t)PW_FIXED_DENSE + ctx->halo, 16);
+    ctx->dense2 = fused && !knob("PFAC_NO_NW4") && !knob("PFAC_NO_DENSE2") && ctx->d1_rows > 0 && ctx->d1_n2 > 0 &&
+                  ctx->num_final <= 65536 && ctx->rec_bytes == 4;
+    ctx->pw_bytes_d = (int)align_up((size_t)(ctx->dense2 ? PW_FIXED_DENSE2 : PW_FIXED_DENSE) + ctx->halo, 16);
     int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
     if (nwd > MAX_WAVES_PER_BLOCK) nwd = MAX_WAVES_PER_BLOCK;
     ctx->waves_per_block_d = nwd;
@@ -2263,7 +2526,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     }
     if (fused && !knob("PFAC_NO_NW4")) {
         ctx->kernel_d = k[3][w8 ? 1 : 0][ctx->root_mode];
-        if (ctx->waves_per_block_d > MAX_WAVES_NW4) {
+        if (!ctx->dense2 && ctx->waves_per_block_d > MAX_WAVES_NW4) {
             ctx->waves_per_block_d = MAX_WAVES_NW4;
             ctx->lds_bytes_d = ctx->shared_bytes + (MAX_WAVES_NW4 - 1) * ctx->pw_bytes_d;
             if (ctx->lds_bytes_d < LDS_TOTAL / 2 + 256) ctx->lds_bytes_d = LDS_TOTAL / 2 + 256;
@@ -2271,6 +2534,10 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel_d, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
     }
     HIP_TRY(ctx, hipFuncSetAttribute(ctx->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(ctx)));
+    if (knob("PFAC_VERBOSE"))
+        fprintf(stderr, "pfac: variant %d fused %d shared LDS %d B; sparse: %d waves x %d B; dense%s: %d waves x %d B; dense rows %d x %d, %d depth-2 states, level-2 filter mode %d\n",
+                ctx->variant, (int)fused, ctx->shared_bytes, ctx->lay[0].waves_per_block, ctx->lay[0].pw_bytes, ctx->dense2 ? " (second form)" : "",
+                ctx->waves_per_block_d, ctx->pw_bytes_d, ctx->d1_rows, ctx->d1_stride, ctx->d1_n2, ctx->l2f_mode);
     return PFAC_OK;
 }
 
@@ -2370,6 +2637,7 @@ void pfac_ctx_destroy(pfac_ctx *ctx) {
         if (s.d_records) (void)hipFree(s.d_records);
         if (s.d_ctl) (void)hipFree(s.d_ctl);
         if (s.d_tile_index) (void)hipFree(s.d_tile_index);
+        if (s.d_d2log) (void)hipFree(s.d_d2log);
         if (s.d_gsum) (void)hipFree(s.d_gsum);
         if (s.d_text) (void)hipFree(s.d_text);
         if (s.d_wide) (void)hipFree(s.d_wide);
@@ -2567,6 +2835,18 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.root_state = ctx->root_state;
         a.stage_cap = dense ? ctx->stage_cap_d : L.stage_cap;
         a.nbuf = dense ? 1u : (unsigned)L.nbuf;
+        a.dense2 = dense && ctx->dense2 ? 1 : 0;
+        a.d2log = nullptr; a.d2log_cap = D2_LOG_CAP;
+        if (a.dense2) {
+            a.stage_cap = 0;                   // (its LDS carve has no staging buffer: a tile it gives up on is counted, then written directly)
+            const size_t words = (size_t)ctx->grid_blocks * (size_t)(wpb - 1) * D2_LOG_CAP;
+            if (s.d2log_words < words) {
+                if (s.d_d2log) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_d2log)); s.d_d2log = nullptr; s.d2log_words = 0; }
+                HIP_TRY(ctx, hipMalloc((void **)&s.d_d2log, words * 4));
+                s.d2log_words = words;
+            }
+            a.d2log = s.d_d2log;
+        }
         a.sparse_cap = ctx->lay[0].stage_cap;
         a.small_cap = ctx->lag2_ok ? ctx->lay[1].stage_cap : ctx->lay[0].stage_cap;
         a.n_tiles = (unsigned)n_tiles;
