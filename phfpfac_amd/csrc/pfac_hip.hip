@@ -188,6 +188,7 @@ struct ScanArgs {
     int n_child;                          // mode 1: 0 (nothing is ever deep), 1 or 2
     const unsigned char *bm2;             // mode 2: bit (b0 << 8 | b1) set iff a path b0 b1 leaves the root
     int bm2_rows, sh_bm2;                 // rows staged in LDS (256, or 1 = the root byte's row) at this LDS offset
+    int sh_t0;                            // packed dense rows: LDS offset of the root table of dense2_tile (256 words), else 0
     const unsigned char *sec2;            // [256]: 1 where the byte is the second byte of some pattern (column OR of bm2)
     int sec_filter;                       // ROOT == 0, mode 2: pre-filter the lookups with sec2 (no 1-byte patterns)
     unsigned stage_cap;                   // records one staging buffer holds (0: final states do not fit the packed word)
@@ -921,12 +922,18 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
 // Log full or more than 15 patterns starting at one offset: the tile is done again by tile_pass (returns ~0u), counted
 // and then written directly (no staging buffer in this layout).  Needs: fused tables, packed dense rows (every depth-1
 // state has a dense row, every depth-2 state an entry in d1.r2), final states below 2^16, 4-byte records.
-constexpr int D2_FB = 2;                       // front-end batches per trip (their LDS round trips overlap)
+#ifndef PFAC_D2_FB
+#define PFAC_D2_FB 2
+#endif
+#ifndef PFAC_D2_NS
+#define PFAC_D2_NS 2
+#endif
+constexpr int D2_FB = PFAC_D2_FB;              // front-end batches per trip (their LDS round trips overlap)
 static_assert(D2_RING >= (D2_FB + 1) * WAVE, "ring: one trip's pushes on top of a batch of left-overs");
 template <bool W8>
-__device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigned char *tile, const int *s0, const Dense1 &d1,
+__device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigned char *tile, const unsigned *t0, const Dense1 &d1,
                                                 unsigned char *aux, unsigned *logg, int lane, unsigned lim, unsigned own_end) {
-    constexpr int NS = 4;                      // walker slots per lane
+    constexpr int NS = PFAC_D2_NS;             // walker slots per lane
     uint2 *ring = reinterpret_cast<uint2 *>(aux);
     const unsigned *t32 = reinterpret_cast<const unsigned *>(tile);
     const int sub = a.wbit - 8;
@@ -940,6 +947,7 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
     for (int w = 0; w < NS; w++) { pos[w] = pn[w] = jn[w] = 0u; s[w] = -1; idx[w] = 0; alive[w] = false; }
     unsigned P0 = 0, head = 0, fcount = 0, lc = 0;             // wave-uniform: next front-end position, ring, log fill
     unsigned jmax = 0;
+    const unsigned no_root = 0xFFFFu | ((unsigned)(a.d1_rows * a.d1_stride) << 16);
     auto lane_rank = [&](unsigned long long b) -> unsigned {
         return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     };
@@ -963,8 +971,8 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
         for (int w = 0; w < NS; w++) { dm[w] = __ballot(!alive[w]); nd += (unsigned)__popcll(dm[w]); }
         // ---- front end: as many trips as the free slots ask for
         while (fcount < nd && P0 < own_end && fcount <= (unsigned)(D2_RING - D2_FB * WAVE)) {
-            unsigned p[D2_FB], win[D2_FB], row[D2_FB], col[D2_FB], s2[D2_FB];
-            int s1[D2_FB], nx[D2_FB];
+            unsigned p[D2_FB], win[D2_FB], rt[D2_FB], col[D2_FB], s2[D2_FB];
+            int nx[D2_FB];
             int2 e2[D2_FB];
             bool a2[D2_FB];
 #pragma unroll
@@ -975,31 +983,31 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
             }
 #pragma unroll
             for (int u = 0; u < D2_FB; u++) {
-                s1[u] = s0[win[u] & 0xFFu];
-                row[u] = d1.idx[win[u] & 0xFFu];
+                rt[u] = t0[win[u] & 0xFFu];
                 col[u] = d1.colmap[(win[u] >> 8) & 0xFFu];
             }
 #pragma unroll
             for (int u = 0; u < D2_FB; u++) {
-                if (p[u] >= own_end) s1[u] = -1;
-                nx[u] = d1.rows[row[u] * (unsigned)a.d1_stride + col[u]];
+                if (p[u] >= own_end) rt[u] = no_root;                            // (the input's last tile only)
+                nx[u] = d1.rows[(rt[u] >> 16) + col[u]];
             }
 #pragma unroll
             for (int u = 0; u < D2_FB; u++) {
-                a2[u] = s1[u] >= 0 && p[u] + 1u < lim && nx[u] >= 0;
+                a2[u] = p[u] + 1u < lim && nx[u] >= 0;
                 e2[u] = d1.r2[a2[u] ? (nx[u] >> D1_STATE_BITS) : 0];             // {r[] of the depth-2 state, its child mask}
                 s2[u] = (unsigned)nx[u] & ((1u << D1_STATE_BITS) - 1u);
             }
 #pragma unroll
             for (int u = 0; u < D2_FB; u++) {
-                const bool fin1 = (unsigned)s1[u] < nfin, fin2 = a2[u] && s2[u] < nfin;
+                const unsigned s1 = rt[u] & 0xFFFFu;
+                const bool fin1 = s1 != 0xFFFFu, fin2 = a2[u] && s2[u] < nfin;
                 const unsigned b2 = (win[u] >> 16) & 0xFFu;
 #ifdef PFAC_ABL_D2NOWALK                       // ablation builds only: nothing goes beyond its second byte (records missing)
                 const bool more = false && a2[u];
 #else
                 const bool more = a2[u] && p[u] + 2u < lim && (((unsigned)e2[u].y >> (b2 & 31u)) & 1u) != 0u;
 #endif
-                log_put(fin1, p[u] | ((unsigned)s1[u] << 16));
+                log_put(fin1, p[u] | (s1 << 16));
                 log_put(fin2, p[u] | (fin1 ? 1u << 12 : 0u) | (s2[u] << 16));
                 const unsigned long long mb = __ballot(more);
                 if (mb) {
@@ -1107,7 +1115,11 @@ __device__ __forceinline__ void dense2_scatter(const ScanArgs &a, unsigned char 
     }
     reinterpret_cast<u32x4 *>(pref2)[lane] = pw;
     wave_lds_sync();
-    unsigned *out = static_cast<unsigned *>(a.out);
+    // the tile's piece of the heap through a buffer descriptor: a scalar base, and what lies past the end of the record
+    // array is dropped by the bounds check
+    const unsigned long long room = base < a.out_cap ? a.out_cap - base : 0ull;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned *>(a.out) + base, 0,
+                                                                         (int)((room < (unsigned long long)cnt ? (unsigned)room : cnt) * 4u), 0x00020000);
 #ifdef PFAC_ABL_D2NOSCATTER                    // ablation builds only: the records never reach the heap
     cnt = 0;
 #endif
@@ -1124,7 +1136,7 @@ __device__ __forceinline__ void dense2_scatter(const ScanArgs &a, unsigned char 
             const unsigned p = e[u] & 0xFFFu, j = (e[u] >> 12) & 15u, st = e[u] >> 16;
             const unsigned x = cntw[p >> 3];
             const unsigned dest = (unsigned)pref[p >> 3] + nibsum(x & ((1u << ((p & 7u) * 4u)) - 1u)) + j;
-            if (i < cnt && base + dest < a.out_cap) out[base + dest] = p | (st << 12);
+            if (i < cnt) __builtin_amdgcn_raw_buffer_store_b32(p | (st << 12), ors, (int)(dest << 2), 0, 0);
         }
     }
 }
@@ -1228,6 +1240,16 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
     } else {
         for (int i = tid; i < 256; i += blockDim.x) { d1idx_l[i] = 0; colmap_l[i] = 0; }
     }
+    if (a.d1_rows > 0)                         // (one more row, without edges: where dense2_tile sends the bytes that start no pattern)
+        for (int i = tid; i < a.d1_stride; i += blockDim.x) d1_l[a.d1_rows * a.d1_stride + i] = -1;
+    // root table of dense2_tile: final state of the byte's depth-1 state (0xFFFF: not final) | word offset of its dense row << 16
+    const unsigned *t0_l = reinterpret_cast<const unsigned *>(smem + a.sh_t0);
+    if (FUSED && NW == 4 && a.sh_t0)
+        for (int i = tid; i < 256; i += blockDim.x) {
+            const int v = a.s0[i];
+            reinterpret_cast<unsigned *>(smem + a.sh_t0)[i] = v >= 0 ? (((unsigned)v < (unsigned)a.num_final ? (unsigned)v : 0xFFFFu) | ((unsigned)(a.d1idx[i] * a.d1_stride) << 16))
+                                                                     : (0xFFFFu | ((unsigned)(a.d1_rows * a.d1_stride) << 16));
+        }
     int2 *d1r2_l = reinterpret_cast<int2 *>(smem + SH_D1 + a.d1_lds_bytes);
     if (FUSED && a.d1_n2 > 0)
         for (int i = tid; i < a.d1_n2; i += blockDim.x) { const int2 e = a.d1r2[i]; d1r2_l[i] = make_int2(e.x + a.rn_bias, e.y); }
@@ -1502,7 +1524,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         if (NW == 4 && FUSED) {
             if (d2) {
                 const unsigned long long own = a.n_owned - tile_base;
-                d2cnt = dense2_tile<W8>(a, tile, s0, d1, aux, d2log, lane, lim, own < (unsigned long long)WTILE ? (unsigned)own : (unsigned)WTILE);
+                d2cnt = dense2_tile<W8>(a, tile, t0_l, d1, aux, d2log, lane, lim, own < (unsigned long long)WTILE ? (unsigned)own : (unsigned)WTILE);
             }
         }
         const bool d2done = d2cnt != ~0u;
@@ -2188,7 +2210,7 @@ struct pfac_ctx {
     int rec_bytes = 4;                    // record form: 2 (<= 16 final states), 4 (<= 2^20), 8 bytes (pfac_record)
     // level-2 filter (ScanArgs::l2f_mode)
     unsigned char *d_bm2 = nullptr;       // 2-byte-prefix bitmap, 256 rows of 32 bytes
-    int l2f_mode = 0, n_child = 0, bm2_rows = 0, sh_bm2 = 0, sec_filter = 0;
+    int l2f_mode = 0, n_child = 0, bm2_rows = 0, sh_bm2 = 0, sec_filter = 0, sh_t0 = 0;
     unsigned child0 = 0, child1 = 0;
     // tuning / test knobs, read from the environment ONCE, when a table is installed
     unsigned spin_max = SPIN_MAX, fault = 0, ticket_ways_knob = 0;
@@ -2343,7 +2365,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
         } else {
             ctx->d1_stride = stride;
             ctx->d1_ncols = ncols;
-            ctx->d1_lds_bytes = (int)align_up((size_t)ctx->d1_rows * ctx->d1_stride * 4, 16);
+            ctx->d1_lds_bytes = (int)align_up((size_t)(ctx->d1_rows + 1) * ctx->d1_stride * 4, 16);   // (+ one row without edges)
             HIP_TRY(ctx, hipMemcpy(b + off_col, colmap, 256, hipMemcpyHostToDevice));
             HIP_TRY(ctx, hipMemcpy(b + off_col + 256, colbyte, 256, hipMemcpyHostToDevice));
         }
@@ -2365,6 +2387,8 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     }
     ctx->shared_bytes = SH_D1 + ctx->d1_lds_bytes + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 8, 16));
     if (fused && ctx->d1_rows == 0) ctx->shared_bytes += 1024;   // r[] of the depth-1 states by root byte
+    ctx->sh_t0 = 0;
+    if (ctx->d1_n2 > 0) { ctx->sh_t0 = ctx->shared_bytes; ctx->shared_bytes += 1024; }   // dense mode, second form: its root table
     // ---- level-2 filter: the 2-byte-prefix bitmap is built on the device from the uploaded tables; a single-edge
     // root with at most two grandchildren gets the bit-parallel form (their bytes), everything else the lookup form
     if (!ctx->d_bm2) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bm2, 256 * 32 + 256));   // bitmap + the second-byte flags
@@ -2468,7 +2492,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     }
     // dense-mode layout
     ctx->dense2 = fused && !knob("PFAC_NO_NW4") && !knob("PFAC_NO_DENSE2") && ctx->d1_rows > 0 && ctx->d1_n2 > 0 &&
-                  ctx->num_final <= 65536 && ctx->rec_bytes == 4;
+                  ctx->num_final <= 65535 && ctx->rec_bytes == 4;
     ctx->pw_bytes_d = (int)align_up((size_t)(ctx->dense2 ? PW_FIXED_DENSE2 : PW_FIXED_DENSE) + ctx->halo, 16);
     int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
     if (nwd > MAX_WAVES_PER_BLOCK) nwd = MAX_WAVES_PER_BLOCK;
@@ -2816,7 +2840,7 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.tile_index = s.d_tile_index;
         a.rec_bytes = (unsigned)ctx->rec_bytes;
         a.l2f_mode = ctx->l2f_mode; a.child0 = ctx->child0; a.child1 = ctx->child1; a.n_child = ctx->n_child;
-        a.bm2 = ctx->d_bm2; a.bm2_rows = ctx->bm2_rows; a.sh_bm2 = ctx->sh_bm2;
+        a.bm2 = ctx->d_bm2; a.bm2_rows = ctx->bm2_rows; a.sh_bm2 = ctx->sh_bm2; a.sh_t0 = ctx->sh_t0;
         a.sec2 = ctx->d_bm2 + 256 * 32; a.sec_filter = ctx->sec_filter;
         a.spin_max = ctx->spin_max; a.fault = ctx->fault;
         a.s0 = ctx->d_s0; a.r = ctx->d_r; a.T = ctx->d_T; a.T4 = ctx->d_T4_alloc; a.rn_bias = ctx->rn_bias;
