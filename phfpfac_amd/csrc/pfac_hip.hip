@@ -2202,6 +2202,7 @@ struct pfac_ctx {
     unsigned stage_cap_d = 0;
     bool dense = false;                   // current staging mode (adapts to the match density seen by the last scan)
     bool dense2 = false;                  // dense mode runs in its second form (dense2_tile): fused tables, packed dense rows, 4-byte records
+    unsigned d2log_cap = 0;               // ... words of record log per compute wave (test knob PFAC_D2_LOGCAP: a smaller one)
     int dense_forced = -1;                // PFAC_DENSE=0/1 pins the mode
     int *d_d1 = nullptr;                  // dense depth-1 rows + (after them) the 256-byte row index
     int d1_rows = 0, d1_stride = 0, d1_ncols = 0, d1_lds_bytes = 0;
@@ -2493,6 +2494,9 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
     // dense-mode layout
     ctx->dense2 = fused && !knob("PFAC_NO_NW4") && !knob("PFAC_NO_DENSE2") && ctx->d1_rows > 0 && ctx->d1_n2 > 0 &&
                   ctx->num_final <= 65535 && ctx->rec_bytes == 4;
+    ctx->d2log_cap = D2_LOG_CAP;
+    const int d2cap_knob = env_int("PFAC_D2_LOGCAP", 0);     // test knob: tiles with more records than this take the fallback pass
+    if (d2cap_knob >= 16 && (unsigned)d2cap_knob < D2_LOG_CAP) ctx->d2log_cap = (unsigned)d2cap_knob;
     ctx->pw_bytes_d = (int)align_up((size_t)(ctx->dense2 ? PW_FIXED_DENSE2 : PW_FIXED_DENSE) + ctx->halo, 16);
     int nwd = (LDS_TOTAL - ctx->shared_bytes) / ctx->pw_bytes_d + 1;
     if (nwd > MAX_WAVES_PER_BLOCK) nwd = MAX_WAVES_PER_BLOCK;
@@ -2860,10 +2864,10 @@ int pfac_scan_async(pfac_ctx *ctx, int slot, const void *d_input, uint64_t n_own
         a.stage_cap = dense ? ctx->stage_cap_d : L.stage_cap;
         a.nbuf = dense ? 1u : (unsigned)L.nbuf;
         a.dense2 = dense && ctx->dense2 ? 1 : 0;
-        a.d2log = nullptr; a.d2log_cap = D2_LOG_CAP;
+        a.d2log = nullptr; a.d2log_cap = ctx->d2log_cap;
         if (a.dense2) {
             a.stage_cap = 0;                   // (its LDS carve has no staging buffer: a tile it gives up on is counted, then written directly)
-            const size_t words = (size_t)ctx->grid_blocks * (size_t)(wpb - 1) * D2_LOG_CAP;
+            const size_t words = (size_t)ctx->grid_blocks * (size_t)(wpb - 1) * ctx->d2log_cap;
             if (s.d2log_words < words) {
                 if (s.d_d2log) { HIP_TRY(ctx, hipStreamSynchronize(s.stream)); HIP_TRY(ctx, hipFree(s.d_d2log)); s.d_d2log = nullptr; s.d2log_words = 0; }
                 HIP_TRY(ctx, hipMalloc((void **)&s.d_d2log, words * 4));

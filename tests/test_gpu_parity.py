@@ -131,10 +131,14 @@ def test_bench_rank_code_at_the_c4_shard_size(tmp_path):
 
 
 @pytest.mark.parametrize("width,env", [(256, {}), (1024, {}), (64, {}), (256, {"PFAC_NO_D1PACK": "1"}),
-                                       (4096, {"PFAC_NO_NW4": "1"}), (256, {"PFAC_NO_FUSE": "1"}), (256, {"PFAC_NO_D1": "1"})])
+                                       (4096, {"PFAC_NO_NW4": "1"}), (256, {"PFAC_NO_FUSE": "1"}), (256, {"PFAC_NO_D1": "1"}),
+                                       (256, {"PFAC_NO_DENSE2": "1"}), (2048, {"PFAC_NO_DENSE2": "1"}),
+                                       (256, {"PFAC_D2_LOGCAP": "64"}), (512, {"PFAC_D2_LOGCAP": "1500"}), (256, {"PFAC_NWB": "4"})])
 def test_dictionary_dense_mode_kernels(width, env, resolve, monkeypatch):
-    """Dense staging mode on L2 tables: the fused-slot kernels with four walks per lane (width >= 256), the
-    unfused two-walk kernel (width 64) and every fallback knob -- all must give the oracle's records."""
+    """Dense staging mode on L2 tables: its second form (refilled walker slots, records ordered on the way out: fused
+    tables with packed dense rows, width >= 256), its fallback pass (a record log too small for the tile), the classic
+    fused-slot kernels with four walks per lane, the unfused two-walk kernel (width 64) and every fallback knob -- all
+    must give the oracle's records."""
     monkeypatch.setenv("PFAC_DENSE", "1")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -143,6 +147,27 @@ def test_dictionary_dense_mode_kernels(width, env, resolve, monkeypatch):
     rec = gpu_records(table, data)
     pos, ids = oracle_pairs(resolve("xaa+xab+xac+xad"), data)
     assert_same(table, rec, pos, ids)
+
+
+def test_dense_mode_more_than_15_patterns_at_one_offset(tmp_path, monkeypatch):
+    """The second form of dense mode counts a position's records in 4 bits: a tile where 16 or more patterns start at
+    one offset is done again the classic way (nested prefixes a, aa, aaa, ... on runs of a), and so is a tile with more
+    records than the wave's log holds; tiles without such an offset in the same input keep the fast path."""
+    monkeypatch.setenv("PFAC_DENSE", "1")
+    monkeypatch.setenv("PFAC_FORCE_L2", "1")
+    pats = [b"a" * k for k in range(1, 25)] + [b"ab", b"abc", b"bca", b"cab", b"b", b"zq", b"qzq"]
+    pf = tmp_path / "nested.pat"
+    pf.write_bytes(b"\n".join(pats) + b"\n")
+    rng = np.random.default_rng(5)
+    data = rng.choice(np.frombuffer(b"abcqz", dtype=np.uint8), 300_000).astype(np.uint8)
+    data[5000:5040] = ord("a")                   # one run of 40: 24 patterns at its first offsets
+    data[150_000:150_018] = ord("a")             # 18 patterns at one offset
+    data[220_000:220_015] = ord("a")             # exactly 15: still the fast path
+    table = PfacTable.from_file(str(pf), 256)
+    rec = gpu_records(table, data.tobytes())
+    pos, ids = oracle_pairs(str(pf), data.tobytes())
+    assert_same(table, rec, pos, ids)
+    assert np.bincount(pos).max() == 24
 
 
 @pytest.mark.parametrize("env", [{"PFAC_FORCE_L2": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_DENSE": "1"},

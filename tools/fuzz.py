@@ -15,7 +15,9 @@ tmp = tempfile.mkdtemp()
 KNOBS = [{}, {"PFAC_FORCE_L2": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_DENSE": "1"}, {"PFAC_DENSE": "1"}, {"PFAC_LAG": "1"},
          {"PFAC_LAG": "2"}, {"PFAC_FORCE_L2": "1", "PFAC_NO_FUSE": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_NO_D1": "1"},
          {"PFAC_REC_BYTES": "4"}, {"PFAC_WIDE": "1"}, {"PFAC_FORCE_L2": "1", "PFAC_NO_NW4": "1", "PFAC_DENSE": "1"},
-         {"PFAC_L2F": "0"}, {"PFAC_L2F": "2"}, {"PFAC_L2F": "3"}, {"PFAC_L2F": "3", "PFAC_FORCE_L2": "1"}, {"PFAC_NO_SECF": "1", "PFAC_FORCE_L2": "1"}, {"PFAC_NWB": "4"}]
+         {"PFAC_L2F": "0"}, {"PFAC_L2F": "2"}, {"PFAC_L2F": "3"}, {"PFAC_L2F": "3", "PFAC_FORCE_L2": "1"}, {"PFAC_NO_SECF": "1", "PFAC_FORCE_L2": "1"}, {"PFAC_NWB": "4"},
+         {"PFAC_FORCE_L2": "1", "PFAC_DENSE": "1", "PFAC_D2_LOGCAP": "64"}, {"PFAC_FORCE_L2": "1", "PFAC_DENSE": "1", "PFAC_NO_DENSE2": "1"},
+         {"PFAC_FORCE_L2": "1", "PFAC_DENSE": "1", "PFAC_NWB": "5"}]
 ALL = sorted({k for d in KNOBS for k in d})
 t0 = t_last = time.time(); cases = 0; recs = 0
 while time.time() - t0 < seconds:
