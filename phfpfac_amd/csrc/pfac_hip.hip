@@ -51,6 +51,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -951,11 +952,28 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
     auto lane_rank = [&](unsigned long long b) -> unsigned {
         return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     };
+    // Log words are collected in LDS (the bytes of the position counts, which only the scatter phase uses) and leave 64 at a
+    // time: a store of a handful of lanes costs the texture path as much as a full one, and a tile logs ~180 handfuls
+    unsigned *stg = reinterpret_cast<unsigned *>(aux + D2_CNT_OFF);
+    constexpr unsigned STG = (unsigned)(WTILE / 2 / 4);        // words (a power of two)
+    static_assert(STG >= (unsigned)(WAVE + 2 * D2_FB * WAVE) && STG >= (unsigned)(WAVE + PFAC_D2_NS * WAVE), "log staging: < 64 words pending + what a trip / a step adds");
+    unsigned fl = 0;                                           // log words flushed so far (a multiple of 64 until the end)
     auto log_put = [&](bool f, unsigned word) {
-        const unsigned long long b = __ballot(f);
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(f);
         if (b) {
-            if (f) __builtin_amdgcn_raw_buffer_store_b32(word, lrs, (int)((lc + lane_rank(b)) << 2), 0, 0);
+            if (f) stg[(lc + lane_rank(b)) & (STG - 1u)] = word;
             lc += (unsigned)__popcll(b);
+        }
+    };
+    auto log_flush = [&](bool all) {
+        if (lc - fl >= (unsigned)WAVE || (all && lc != fl)) {
+            wave_lds_sync();
+            while (lc - fl >= (unsigned)WAVE) {
+                __builtin_amdgcn_raw_buffer_store_b32(stg[(fl + (unsigned)lane) & (STG - 1u)], lrs, (int)((fl + (unsigned)lane) << 2), 0, 0);
+                fl += WAVE;
+            }
+            if (all && fl + (unsigned)lane < lc)
+                __builtin_amdgcn_raw_buffer_store_b32(stg[(fl + (unsigned)lane) & (STG - 1u)], lrs, (int)((fl + (unsigned)lane) << 2), 0, 0);
         }
     };
     auto slot = [&](int i) -> int4 {
@@ -964,60 +982,70 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
     auto slot_of = [&](int rnv, unsigned st, unsigned byte) -> int {       // fused slot of (state, byte), r[row of state] given
         return W8 ? rnv + (int)byte : rnv + (int)(((st & ((1u << sub) - 1u)) << 8) | byte);
     };
+    // One trip of the front end: D2_FB x 64 positions from P0 on.  EDGE: the input's last tile (positions past n_owned start
+    // nothing, bytes past the input are not read) -- everywhere else a position's first three bytes are inside the tile + halo
+    // and those tests fall away.  A byte that starts no pattern has the no-edge row, a (first, second) byte pair that is no
+    // prefix the no-child entry of d1.r2: "no second state" needs no test of its own.
+    const bool edge = own_end < (unsigned)WTILE || lim < (unsigned)WTILE + 3u;
+    const unsigned n2 = (unsigned)a.d1_n2;
+    auto front = [&](auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        unsigned p[D2_FB], win[D2_FB], rt[D2_FB], col[D2_FB];
+        int nx[D2_FB];
+        int2 e2[D2_FB];
+#pragma unroll
+        for (int u = 0; u < D2_FB; u++) {
+            p[u] = P0 + (unsigned)(u * WAVE + lane);
+            const unsigned lo = t32[p[u] >> 2], hi = t32[(p[u] >> 2) + 1];
+            win[u] = __builtin_amdgcn_alignbyte(hi, lo, p[u] & 3u);              // bytes p .. p+3
+        }
+#pragma unroll
+        for (int u = 0; u < D2_FB; u++) {
+            rt[u] = t0[win[u] & 0xFFu];
+            col[u] = d1.colmap[(win[u] >> 8) & 0xFFu];
+        }
+#pragma unroll
+        for (int u = 0; u < D2_FB; u++) {
+            if (EDGE && p[u] >= own_end) rt[u] = no_root;
+            nx[u] = d1.rows[(rt[u] >> 16) + col[u]];                             // depth-2 state | index of its r2 entry << 20, or -1
+        }
+#pragma unroll
+        for (int u = 0; u < D2_FB; u++) {
+            if (EDGE && p[u] + 1u >= lim) nx[u] = -1;
+            const unsigned ri = (unsigned)(nx[u] >> D1_STATE_BITS);             // (-1: beyond every index)
+            e2[u] = d1.r2[ri < n2 ? ri : n2];                                    // {r[] of the depth-2 state, its child mask}; entry n2: {0, 0}
+        }
+#pragma unroll
+        for (int u = 0; u < D2_FB; u++) {
+            const unsigned s1 = rt[u] & 0xFFFFu, s2 = (unsigned)nx[u] & ((1u << D1_STATE_BITS) - 1u);
+            const bool fin1 = s1 != 0xFFFFu, fin2 = s2 < nfin;                   // (no second state: s2 = 2^20 - 1, above every final state)
+            const unsigned b2 = (win[u] >> 16) & 0xFFu;
+#ifdef PFAC_ABL_D2NOWALK                       // ablation builds only: nothing goes beyond its second byte (records missing)
+            const bool more = false && b2;
+#else
+            const bool more = (((unsigned)e2[u].y >> (b2 & 31u)) & 1u) != 0u && (!EDGE || p[u] + 2u < lim);
+#endif
+            log_put(fin1, p[u] | (s1 << 16));
+            log_put(fin2, p[u] | (fin1 ? 1u << 12 : 0u) | ((unsigned)nx[u] << 16));
+            const unsigned long long mb = __builtin_amdgcn_ballot_w64(more);
+            if (mb) {
+                const unsigned n12 = (fin1 ? 1u : 0u) + (fin2 ? 1u : 0u);
+                if (more) ring[(head + fcount + lane_rank(mb)) & (unsigned)(D2_RING - 1)] =
+                    make_uint2(p[u] | ((unsigned)nx[u] << 12), (unsigned)slot_of(e2[u].x, s2, b2) | (n12 << 28));
+                fcount += (unsigned)__popcll(mb);
+            }
+        }
+        P0 += D2_FB * WAVE;
+    };
     for (;;) {
         unsigned long long dm[NS];
         unsigned nd = 0;
 #pragma unroll
-        for (int w = 0; w < NS; w++) { dm[w] = __ballot(!alive[w]); nd += (unsigned)__popcll(dm[w]); }
+        for (int w = 0; w < NS; w++) { dm[w] = __builtin_amdgcn_ballot_w64(!alive[w]); nd += (unsigned)__popcll(dm[w]); }
         // ---- front end: as many trips as the free slots ask for
         while (fcount < nd && P0 < own_end && fcount <= (unsigned)(D2_RING - D2_FB * WAVE)) {
-            unsigned p[D2_FB], win[D2_FB], rt[D2_FB], col[D2_FB], s2[D2_FB];
-            int nx[D2_FB];
-            int2 e2[D2_FB];
-            bool a2[D2_FB];
-#pragma unroll
-            for (int u = 0; u < D2_FB; u++) {
-                p[u] = P0 + (unsigned)(u * WAVE + lane);
-                const unsigned lo = t32[p[u] >> 2], hi = t32[(p[u] >> 2) + 1];
-                win[u] = __builtin_amdgcn_alignbyte(hi, lo, p[u] & 3u);          // bytes p .. p+3
-            }
-#pragma unroll
-            for (int u = 0; u < D2_FB; u++) {
-                rt[u] = t0[win[u] & 0xFFu];
-                col[u] = d1.colmap[(win[u] >> 8) & 0xFFu];
-            }
-#pragma unroll
-            for (int u = 0; u < D2_FB; u++) {
-                if (p[u] >= own_end) rt[u] = no_root;                            // (the input's last tile only)
-                nx[u] = d1.rows[(rt[u] >> 16) + col[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < D2_FB; u++) {
-                a2[u] = p[u] + 1u < lim && nx[u] >= 0;
-                e2[u] = d1.r2[a2[u] ? (nx[u] >> D1_STATE_BITS) : 0];             // {r[] of the depth-2 state, its child mask}
-                s2[u] = (unsigned)nx[u] & ((1u << D1_STATE_BITS) - 1u);
-            }
-#pragma unroll
-            for (int u = 0; u < D2_FB; u++) {
-                const unsigned s1 = rt[u] & 0xFFFFu;
-                const bool fin1 = s1 != 0xFFFFu, fin2 = a2[u] && s2[u] < nfin;
-                const unsigned b2 = (win[u] >> 16) & 0xFFu;
-#ifdef PFAC_ABL_D2NOWALK                       // ablation builds only: nothing goes beyond its second byte (records missing)
-                const bool more = false && a2[u];
-#else
-                const bool more = a2[u] && p[u] + 2u < lim && (((unsigned)e2[u].y >> (b2 & 31u)) & 1u) != 0u;
-#endif
-                log_put(fin1, p[u] | (s1 << 16));
-                log_put(fin2, p[u] | (fin1 ? 1u << 12 : 0u) | (s2[u] << 16));
-                const unsigned long long mb = __ballot(more);
-                if (mb) {
-                    const unsigned n12 = (fin1 ? 1u : 0u) + (fin2 ? 1u : 0u);
-                    if (more) ring[(head + fcount + lane_rank(mb)) & (unsigned)(D2_RING - 1)] =
-                        make_uint2(p[u] | (s2[u] << 12), (unsigned)slot_of(e2[u].x, s2[u], b2) | (n12 << 28));
-                    fcount += (unsigned)__popcll(mb);
-                }
-            }
-            P0 += D2_FB * WAVE;
+            if (edge) front(std::true_type{}); else front(std::false_type{});
+            log_flush(false);
         }
         if (nd == (unsigned)(NS * WAVE) && fcount == 0u) break;        // no walker left, none pending, every position seen
         wave_lds_sync();
@@ -1064,7 +1092,9 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
             s[w] = sn;
             idx[w] = slot_of(e4[w].z, (unsigned)sn, nb[w]);
         }
+        log_flush(false);
     }
+    log_flush(true);
     if (__any(jmax > 15u) || lc > logcap) return ~0u;
     return lc;
 }
@@ -1077,13 +1107,82 @@ __device__ __forceinline__ void dense2_scatter(const ScanArgs &a, unsigned char 
     unsigned *pref2 = reinterpret_cast<unsigned *>(aux + D2_PREF_OFF);            // u16 pairs
     const unsigned short *pref = reinterpret_cast<const unsigned short *>(aux + D2_PREF_OFF);
     auto nibsum = [](unsigned x) -> unsigned { return (((x & 0x0F0F0F0Fu) + ((x >> 4) & 0x0F0F0F0Fu)) * 0x01010101u) >> 24; };
-    constexpr int UN = 4;                      // log words in flight per lane
+    constexpr int UN = 4;                      // log words per lane per group
+    constexpr int ER = 32;                     // a tile of up to ER x 64 records keeps its log words in registers between the two passes
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     reinterpret_cast<u32x4 *>(cntw)[lane] = zero4;
     reinterpret_cast<u32x4 *>(cntw)[lane + WAVE] = zero4;
     // (the log was written by other lanes of THIS wave: the workgroup-scope fence waits for their stores, and a CU's L1 is
     // coherent with the stores of its own waves -- an agent-scope release would write the whole L2 back, per tile)
     wave_lds_sync();
+    // the tile's piece of the heap through a buffer descriptor: a scalar base, and what lies past the end of the record
+    // array is dropped by the bounds check
+    const unsigned long long room = base < a.out_cap ? a.out_cap - base : 0ull;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned *>(a.out) + base, 0,
+                                                                         (int)((room < (unsigned long long)cnt ? (unsigned)room : cnt) * 4u), 0x00020000);
+    auto count_one = [&](unsigned e) { atomicAdd(&cntw[(e & 0xFFFu) >> 3], 1u << ((e & 7u) * 4u)); };
+    auto prefix = [&]() {
+        wave_lds_sync();
+        const u32x4 x0 = reinterpret_cast<const u32x4 *>(cntw)[2 * lane], x1 = reinterpret_cast<const u32x4 *>(cntw)[2 * lane + 1];
+        unsigned sm[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sm[k] = nibsum(x0[k]); sm[4 + k] = nibsum(x1[k]); }
+        unsigned tot = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) tot += sm[k];
+        unsigned run = wave_incl_scan(tot) - tot;
+        u32x4 pw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned lo = run; run += sm[2 * k];
+            const unsigned hi = run; run += sm[2 * k + 1];
+            pw[k] = lo | (hi << 16);
+        }
+        reinterpret_cast<u32x4 *>(pref2)[lane] = pw;
+        wave_lds_sync();
+    };
+    auto place_one = [&](unsigned e) {
+        const unsigned p = e & 0xFFFu, j = (e >> 12) & 15u, st = e >> 16;
+        const unsigned x = cntw[p >> 3];
+        const unsigned dest = (unsigned)pref[p >> 3] + nibsum(x & ((1u << ((p & 7u) * 4u)) - 1u)) + j;
+        __builtin_amdgcn_raw_buffer_store_b32(p | (st << 12), ors, (int)(dest << 2), 0, 0);
+    };
+    if (cnt <= (unsigned)(ER * WAVE)) {
+        const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(logg), 0, (int)(cnt * 4u), 0x00020000);
+        // the usual tile: every load of the log goes out before the first word is looked at -- the head of the log has left
+        // the L2 by now (one memory latency per tile, not one per group of loads) -- and the words stay in registers for
+        // the second pass
+        unsigned e[ER];
+#pragma unroll
+        for (int g = 0; g < ER / UN; g++) {
+            if ((unsigned)(g * UN * WAVE) < cnt) {
+#pragma unroll
+                for (int u = 0; u < UN; u++)      // (one lane offset, the group in the scalar offset; past the end of the log: 0)
+                    e[g * UN + u] = __builtin_amdgcn_raw_buffer_load_b32(lrs, lane * 4, (g * UN + u) * WAVE * 4, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < ER / UN; g++) {
+            if ((unsigned)(g * UN * WAVE) < cnt) {
+#pragma unroll
+                for (int u = 0; u < UN; u++)
+                    if ((unsigned)((g * UN + u) * WAVE + lane) < cnt) count_one(e[g * UN + u]);
+            }
+        }
+        prefix();
+#ifdef PFAC_ABL_D2NOSCATTER                    // ablation builds only: the records never reach the heap
+        cnt = 0;
+#endif
+#pragma unroll
+        for (int g = 0; g < ER / UN; g++) {
+            if ((unsigned)(g * UN * WAVE) < cnt) {
+#pragma unroll
+                for (int u = 0; u < UN; u++)
+                    if ((unsigned)((g * UN + u) * WAVE + lane) < cnt) place_one(e[g * UN + u]);
+            }
+        }
+        return;
+    }
     for (unsigned i0 = 0; i0 < cnt; i0 += UN * WAVE) {
         unsigned e[UN];
 #pragma unroll
@@ -1092,35 +1191,11 @@ __device__ __forceinline__ void dense2_scatter(const ScanArgs &a, unsigned char 
             e[u] = i < cnt ? logg[i] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const unsigned i = i0 + (unsigned)(u * WAVE + lane);
-            if (i < cnt) atomicAdd(&cntw[(e[u] & 0xFFFu) >> 3], 1u << ((e[u] & 7u) * 4u));
-        }
+        for (int u = 0; u < UN; u++)
+            if (i0 + (unsigned)(u * WAVE + lane) < cnt) count_one(e[u]);
     }
-    wave_lds_sync();
-    const u32x4 x0 = reinterpret_cast<const u32x4 *>(cntw)[2 * lane], x1 = reinterpret_cast<const u32x4 *>(cntw)[2 * lane + 1];
-    unsigned sm[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { sm[k] = nibsum(x0[k]); sm[4 + k] = nibsum(x1[k]); }
-    unsigned tot = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) tot += sm[k];
-    unsigned run = wave_incl_scan(tot) - tot;
-    u32x4 pw;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const unsigned lo = run; run += sm[2 * k];
-        const unsigned hi = run; run += sm[2 * k + 1];
-        pw[k] = lo | (hi << 16);
-    }
-    reinterpret_cast<u32x4 *>(pref2)[lane] = pw;
-    wave_lds_sync();
-    // the tile's piece of the heap through a buffer descriptor: a scalar base, and what lies past the end of the record
-    // array is dropped by the bounds check
-    const unsigned long long room = base < a.out_cap ? a.out_cap - base : 0ull;
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned *>(a.out) + base, 0,
-                                                                         (int)((room < (unsigned long long)cnt ? (unsigned)room : cnt) * 4u), 0x00020000);
-#ifdef PFAC_ABL_D2NOSCATTER                    // ablation builds only: the records never reach the heap
+    prefix();
+#ifdef PFAC_ABL_D2NOSCATTER
     cnt = 0;
 #endif
     for (unsigned i0 = 0; i0 < cnt; i0 += UN * WAVE) {
@@ -1131,13 +1206,8 @@ __device__ __forceinline__ void dense2_scatter(const ScanArgs &a, unsigned char 
             e[u] = i < cnt ? logg[i] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const unsigned i = i0 + (unsigned)(u * WAVE + lane);
-            const unsigned p = e[u] & 0xFFFu, j = (e[u] >> 12) & 15u, st = e[u] >> 16;
-            const unsigned x = cntw[p >> 3];
-            const unsigned dest = (unsigned)pref[p >> 3] + nibsum(x & ((1u << ((p & 7u) * 4u)) - 1u)) + j;
-            if (i < cnt) __builtin_amdgcn_raw_buffer_store_b32(p | (st << 12), ors, (int)(dest << 2), 0, 0);
-        }
+        for (int u = 0; u < UN; u++)
+            if (i0 + (unsigned)(u * WAVE + lane) < cnt) place_one(e[u]);
     }
 }
 
@@ -1252,7 +1322,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
         }
     int2 *d1r2_l = reinterpret_cast<int2 *>(smem + SH_D1 + a.d1_lds_bytes);
     if (FUSED && a.d1_n2 > 0)
-        for (int i = tid; i < a.d1_n2; i += blockDim.x) { const int2 e = a.d1r2[i]; d1r2_l[i] = make_int2(e.x + a.rn_bias, e.y); }
+        for (int i = tid; i <= a.d1_n2; i += blockDim.x) {     // (one more entry, {0, no child}: where dense2_tile sends "no second state")
+            const int2 e = i < a.d1_n2 ? a.d1r2[i] : make_int2(-a.rn_bias, 0);
+            d1r2_l[i] = make_int2(e.x + a.rn_bias, e.y);
+        }
     // FUSED without dense rows: r[] of the depth-1 states by root byte, in the (unused) dense-row region
     int *s0r_l = reinterpret_cast<int *>(smem + SH_D1);
     const bool have_s0r = FUSED && a.d1_rows == 0;
@@ -2386,7 +2459,7 @@ int configure_kernel(pfac_ctx *ctx, const int32_t *s0_host) {
             }
         }
     }
-    ctx->shared_bytes = SH_D1 + ctx->d1_lds_bytes + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)ctx->d1_n2 * 8, 16));
+    ctx->shared_bytes = SH_D1 + ctx->d1_lds_bytes + (ctx->variant == 0 ? (int)align_up(tbytes, 16) : (int)align_up((size_t)(ctx->d1_n2 ? ctx->d1_n2 + 1 : 0) * 8, 16));
     if (fused && ctx->d1_rows == 0) ctx->shared_bytes += 1024;   // r[] of the depth-1 states by root byte
     ctx->sh_t0 = 0;
     if (ctx->d1_n2 > 0) { ctx->sh_t0 = ctx->shared_bytes; ctx->shared_bytes += 1024; }   // dense mode, second form: its root table
