@@ -725,7 +725,9 @@ int main(int argc, char *argv[]) {
         if (m != MAP_FAILED) {
             g_map = (unsigned char *)m;
             g_map_len = ((uint64_t)st.st_size + 4095) & ~4095ull;
-            const uint64_t per = (256ull << 20) / chunk;
+            const char *pm = getenv("PFAC_PIECE_MB");               /* bytes registered per hipHostRegister call (default 256 MiB) */
+            const uint64_t piece = pm && atoi(pm) > 0 ? (uint64_t)atoi(pm) << 20 : 256ull << 20;
+            const uint64_t per = piece / chunk;
             g_piece_bytes = chunk * (per ? per : 1);             /* whole chunks: a chunk's own bytes never straddle two registrations */
             g_n_pieces = (int)((g_map_len + g_piece_bytes - 1) / g_piece_bytes);
             g_piece_left = (int *)calloc((size_t)g_n_pieces + 1, sizeof(int));
