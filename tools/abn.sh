@@ -21,6 +21,8 @@ declare -A ABL=(
   [nolds]="-DPFAC_ABL_NOLDSCOPY"     # the tile never reaches LDS
   [nocoord]="-DPFAC_ABL_NOCOORD"     # static tiles, no coordinator wave, counts dropped
   [static]="-DPFAC_ABL_STATIC"       # batches dealt round-robin instead of by ticket
+  [d2nowalk]="-DPFAC_ABL_D2NOWALK"   # dense mode, second form: nothing goes beyond its second byte (front end + scatter only)
+  [d2noscat]="-DPFAC_ABL_D2NOSCATTER" # dense mode, second form: the records never leave the log
 )
 set -e
 export PFAC_ENABLE_KNOBS=1
