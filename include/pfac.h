@@ -312,7 +312,8 @@ int pfac_fill_random(pfac_ctx *ctx, int slot, void *d_dst, uint64_t n, uint64_t 
 int pfac_scan_info(pfac_ctx *ctx, int *variant, int *tile_bytes, int *grid_blocks, int *lds_bytes);
 /* ... and the staging layout the NEXT scan will use: buffers per wave (3 / 2: a tile's records leave two / one
  * round(s) after it was scanned; 1: dense mode, emitted at once) and records per buffer (a tile with more is
- * walked a second time).  The layout follows the match density of the scans before. */
+ * walked a second time; 4096 = dense mode's second form, where it is the wave's record log in device memory that
+ * bounds a tile).  The layout follows the match density of the scans before. */
 int pfac_scan_staging(pfac_ctx *ctx, int *buffers, uint32_t *records_per_buffer);
 
 /* ------------------------------------------------------------------ */

@@ -3301,7 +3301,8 @@ int pfac_scan_staging(pfac_ctx *ctx, int *buffers, uint32_t *records_per_buffer)
     if (!ctx->have_table) return fail(ctx, PFAC_E_STATE, "no table uploaded");
     const bool dense = ctx->dense && ctx->stage_cap_d;
     if (buffers) *buffers = dense ? 1 : ctx->sparse().nbuf;
-    if (records_per_buffer) *records_per_buffer = dense ? ctx->stage_cap_d : ctx->sparse().stage_cap;
+    // (dense mode's second form has no staging buffer: what bounds a tile there is the wave's record log)
+    if (records_per_buffer) *records_per_buffer = dense ? (ctx->dense2 ? ctx->d2log_cap : ctx->stage_cap_d) : ctx->sparse().stage_cap;
     return PFAC_OK;
 }
 

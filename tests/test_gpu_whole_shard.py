@@ -90,9 +90,11 @@ def test_second_scan_in_adapted_staging_mode_keeps_parity(tmp_path):
         n1 = g.scan_resident(N, N, d_input=buf)
         c1 = g.checksum(n1)
         after = g.info()["staging_buffers"]
+        after_records = g.info()["staging_records"]
         n2 = g.scan_resident(N, N, d_input=buf)
         c2 = g.checksum(n2)
         host = buf[:N].cpu().numpy()
     cnt, want = ac_whole_shard(ppath, host)
     assert before != after == 1          # sparse layout first, dense (one buffer) afterwards
+    assert after_records == 4096         # ... in its second form (refilled walker slots, record log): not the classic fallback
     assert (n1, c1) == (cnt, want) and (n2, c2) == (cnt, want)
