@@ -909,17 +909,19 @@ __device__ __forceinline__ void copy_out(const ScanArgs &a, const unsigned *stag
 // fifth of the lane-steps of such a round belong to a live walker -- because a round's records have to come out in
 // (position, length) order, and its 8 KiB staging buffer per wave leaves room for 9 waves per CU.  Here the order is
 // made afterwards, and the records wait in device memory, not in LDS (15 waves per CU):
-//   * front end, D2_FB x 64 consecutive positions per trip, every lane busy: first state (root row), second state (dense
-//     row of the depth-1 state: s0 / d1idx / colmap -> rows -> packed {r[], child mask}: three dependent LDS trips), their
-//     final states logged at once; the positions whose depth-2 state has an edge on a byte congruent to the third one
-//     (child mask) go into a ring of pending walkers {position, state, r[], records so far};
-//   * four walker slots per lane; a slot whose walk has ended takes the next ring entry, so the gathers of a step
+//   * front end, D2_FB x 64 consecutive positions per trip, every lane busy: root table (final state of the first byte |
+//     word offset of its dense row), column of the second byte -> dense row entry -> packed {r[], child mask}: three
+//     dependent LDS trips; the final states of depth 1 and 2 are logged at once; the positions whose depth-2 state has an
+//     edge on a byte congruent to the third one (child mask) go into a ring of pending walkers {position, state, fused
+//     slot of the first gather, records so far};
+//   * PFAC_D2_NS walker slots per lane; a slot whose walk has ended takes the next ring entry, so the gathers of a step
 //     belong to live walkers only; a walker dies WITHOUT the gather that would say so when the child mask of its state
 //     has no bit for the next byte; every final state is logged as {position, k-th record of the position, state};
-//   * the log is the wave's own scratch in device memory (written 64 words at a time, read back once: it stays in L2);
-//   * once the tile is done the log is read twice: the records of every position are counted (4-bit fields in LDS), the
-//     counts prefix-summed (per 8 positions + a nibble sum inside the word), and every log entry is stored straight to
-//     its place in the heap: base + prefix[position] + k.
+//   * the log is the wave's own scratch in device memory, written 64 words at a time from an LDS staging area (a store of
+//     a handful of lanes costs the texture path as much as a full one);
+//   * once the tile is done the log is read back (into registers, where it fits): the records of every position are
+//     counted (4-bit fields in LDS), the counts prefix-summed (per 8 positions + a nibble sum inside the word), and every
+//     log entry is stored straight to its place in the heap: base + prefix[position] + k.
 // Log full or more than 15 patterns starting at one offset: the tile is done again by tile_pass (returns ~0u), counted
 // and then written directly (no staging buffer in this layout).  Needs: fused tables, packed dense rows (every depth-1
 // state has a dense row, every depth-2 state an entry in d1.r2), final states below 2^16, 4-byte records.
