@@ -74,13 +74,14 @@ def test_whole_shard_4gib_with_halo_equals_serial_ac(name, tmp_path):
 
 def test_second_scan_in_adapted_staging_mode_keeps_parity(tmp_path):
     """The dictionary on text makes the context switch to dense staging after its first scan (DESIGN.md section 3);
-    the scan that runs in the adapted mode must produce the same whole-shard count and checksum."""
+    the scan that runs in the adapted mode -- dense mode's second form, at BASELINE size -- must produce the same
+    whole-shard count and checksum."""
     import torch
     pat_name, kind, _ = bench.WORKLOADS["text1g_dictionary"]
     ppath = bench.pattern_path(pat_name, str(tmp_path))
     para = open(os.path.join(bench.DATA, "paragraph402"), "rb").read()
     table = PfacTable.from_file(ppath, 256)
-    N = 256 << 20
+    N = GIB
     with GpuMatcher(0, 1) as g:
         g.load_table(table)
         buf = torch.empty(N + 4096, dtype=torch.uint8, device="cuda:0")
