@@ -1039,16 +1039,27 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
         }
         P0 += D2_FB * WAVE;
     };
+#ifdef PFAC_TRACE_BUILD                        // diagnostic build only: where a tile's time goes (compute wave 0 of the first 8 workgroups)
+    unsigned long long tq_front = 0, tq_iter = 0, tq_n = 0;
+    const unsigned long long tq_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (;;) {
         unsigned long long dm[NS];
         unsigned nd = 0;
 #pragma unroll
         for (int w = 0; w < NS; w++) { dm[w] = __builtin_amdgcn_ballot_w64(!alive[w]); nd += (unsigned)__popcll(dm[w]); }
+#ifdef PFAC_TRACE_BUILD
+        const unsigned long long tq_a = __builtin_amdgcn_s_memrealtime();
+#endif
         // ---- front end: as many trips as the free slots ask for
         while (fcount < nd && P0 < own_end && fcount <= (unsigned)(D2_RING - D2_FB * WAVE)) {
             if (edge) front(std::true_type{}); else front(std::false_type{});
             log_flush(false);
         }
+#ifdef PFAC_TRACE_BUILD
+        tq_front += __builtin_amdgcn_s_memrealtime() - tq_a;
+        tq_n++;
+#endif
         if (nd == (unsigned)(NS * WAVE) && fcount == 0u) break;        // no walker left, none pending, every position seen
         wave_lds_sync();
         // ---- free slots take the pending walkers
@@ -1097,6 +1108,14 @@ __device__ __forceinline__ unsigned dense2_tile(const ScanArgs &a, const unsigne
         log_flush(false);
     }
     log_flush(true);
+#ifdef PFAC_TRACE_BUILD
+    if (a.dbg && blockIdx.x < 8 && lane == 0 && (threadIdx.x >> 6) == 0) {
+        unsigned long long *acc = a.dbg + (size_t)blockIdx.x * 64 * 32 + 10;      // columns 10..14 of the block's row 0
+        const unsigned long long tq_all = __builtin_amdgcn_s_memrealtime() - tq_t0;
+        acc[0] += tq_front; acc[1] += tq_n; acc[2] += tq_all; acc[3] += 1; acc[4] += lc;
+    }
+    (void)tq_iter;
+#endif
     if (__any(jmax > 15u) || lc > logcap) return ~0u;
     return lc;
 }
@@ -1603,6 +1622,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             }
         }
         const bool d2done = d2cnt != ~0u;
+        PFAC_STAMP(trace && r > 0 && d2, 12);
         if (!d2done) {
 #pragma unroll
         for (int j = 0; j < MSUBS; j++) {
@@ -1747,8 +1767,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, unsigned char *smem
             const unsigned long long base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
                                             __builtin_amdgcn_readfirstlane((unsigned)v);
             if (lane == 0) a.tile_index[t] = base | ((unsigned long long)cnt << TIX_CNT_SHIFT);
-            if (NW == 4 && FUSED && d2done)
+            PFAC_STAMP(trace && r > 0 && d2, 13);
+            if (NW == 4 && FUSED && d2done) {
                 dense2_scatter(a, aux, d2log, (unsigned)cnt, base, lane);
+                PFAC_STAMP(trace && r > 0, 14);
+            }
             else if (overflow)
                 // staging overflowed (or the automaton is too large for packed staging): walk the tile again,
                 // while its bytes are still in LDS, writing straight to global memory

@@ -70,6 +70,18 @@ if ent.any():
     print("  (rounds traced per workgroup:", n_rounds, "; at most 64)")
 
 acc = d[:, 0, 10:15].sum(axis=0).astype(float)
-if acc[3]:
+rows2 = [d[0][r] for r in range(4, 60) if d[0][r, 4] and d[0][r, 12] and d[0][r, 13] and d[0][r, 14]]
+if rows2:
+    # dense mode's second form: the accumulators and the fine stamps mean something else there
+    print("dense mode, second form -- wave 0 of workgroup 0, mean per tile (us):",
+          {"load wait + lds write": round(float(np.mean([r_[5] - r_[4] for r_ in rows2])) / 100, 2),
+           "probe + next loads": round(float(np.mean([r_[10] - r_[5] for r_ in rows2])) / 100, 2),
+           "dense2_tile": round(float(np.mean([r_[12] - r_[10] for r_ in rows2])) / 100, 2),
+           "count posted + heap atomic back": round(float(np.mean([r_[13] - r_[12] for r_ in rows2])) / 100, 2),
+           "scatter": round(float(np.mean([r_[14] - r_[13] for r_ in rows2])) / 100, 2),
+           "tile to tile": round(float(np.mean(np.diff([d[0][r, 4] for r in range(4, 60) if d[0][r, 4]]))) / 100, 2)})
+    print(f"  inside dense2_tile (8 workgroups, whole launch): {acc[3]:.0f} tiles, {acc[2] / acc[3] / 100:.2f} us per tile, of it front end "
+          f"{acc[0] / acc[3] / 100:.2f} us; {acc[1] / acc[3]:.1f} walk iterations per tile at {(acc[2] - acc[0]) / max(acc[1], 1) / 100:.2f} us each; {acc[4] / acc[3]:.0f} records per tile")
+elif acc[3]:
     print(f"tile_pass of compute wave 0 (8 workgroups, whole launch): {acc[3]:.0f} tiles with FIFO work, {acc[1] / acc[3]:.2f} rounds per tile, "
           f"{acc[0] / max(acc[1], 1) / 100:.2f} us per round, {acc[2] / acc[3] / 100:.2f} us per tile_pass (rounds {acc[0] / acc[3] / 100:.2f} us), last-round entries {acc[4] / acc[3]:.1f}")
